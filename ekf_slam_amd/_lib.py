@@ -1,0 +1,94 @@
+"""ctypes binding of libekfslam.so -- exactly the symbols include/ekfslam.h declares.
+
+There is no CPU or PyTorch fallback: if the shared library is missing this raises, and on a machine
+without a HIP device ``ekf_create`` returns EKF_ERR_NO_DEVICE (surfaced as ``EkfError``).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libekfslam.so")
+
+EKF_OK = 0
+EKF_ERR_INVALID_ARG, EKF_ERR_NO_DEVICE, EKF_ERR_HIP, EKF_ERR_CAPACITY = 1, 2, 3, 4
+EKF_ERR_INDEX, EKF_ERR_LOOKUP, EKF_ERR_STATE, EKF_ERR_COMM = 5, 6, 7, 8
+EKF_MODE_KNOWN, EKF_MODE_UC = 0, 1
+EKF_STORE_F64, EKF_STORE_F32 = 0, 1
+(EKF_KERNEL_DOWNDATE, EKF_KERNEL_GATHER, EKF_KERNEL_PREDICT, EKF_KERNEL_ASSOCIATE, EKF_KERNEL_APPEND,
+ EKF_KERNEL_COUNT) = range(6)
+
+_d = ctypes.c_double
+_dp = ctypes.POINTER(ctypes.c_double)
+_i32 = ctypes.c_int32
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+
+
+class EkfConfig(ctypes.Structure):
+    """struct ekf_config (include/ekfslam.h)."""
+    _fields_ = [("C", _d), ("Rc", _d * 2), ("s_cost", _d), ("s_thresh", _d), ("w_pos", _d),
+                ("capacity_landmarks", _i64), ("mode", _i32), ("storage", _i32), ("device", _i32),
+                ("tile", _i32), ("rank", _i32), ("world", _i32), ("reserved", _i32 * 8)]
+
+
+# name -> (restype, argtypes); every symbol of include/ekfslam.h
+SIGNATURES = {
+    "ekf_abi_version": (_i32, []),
+    "ekf_status_string": (ctypes.c_char_p, [_i32]),
+    "ekf_config_default": (_i32, [ctypes.POINTER(EkfConfig), _i32]),
+    "ekf_create": (_i32, [ctypes.POINTER(EkfConfig), ctypes.POINTER(_vp)]),
+    "ekf_destroy": (_i32, [_vp]),
+    "ekf_last_error": (ctypes.c_char_p, [_vp]),
+    "ekf_set_stream": (_i32, [_vp, _vp]),
+    "ekf_sync": (_i32, [_vp]),
+    "ekf_predict": (_i32, [_vp, _dp]),
+    "ekf_motion_model": (_i32, [_dp, _i64, _dp, _dp, _dp]),
+    "ekf_append": (_i32, [_vp, _dp, _dp, _dp, _d]),
+    "ekf_correct": (_i32, [_vp, _dp, _dp, _i64]),
+    "ekf_associate": (_i32, [_vp, _dp, _dp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), _dp, _dp]),
+    "ekf_measure": (_i32, [_vp, _dp, _i64, _dp, _dp, _dp, _i64]),
+    "ekf_num_landmarks": (_i32, [_vp, ctypes.POINTER(_i64)]),
+    "ekf_get_x": (_i32, [_vp, _dp]),
+    "ekf_set_x": (_i32, [_vp, _dp, _i64]),
+    "ekf_get_s": (_i32, [_vp, _dp]),
+    "ekf_set_s": (_i32, [_vp, _dp, _i64]),
+    "ekf_get_P": (_i32, [_vp, _dp]),
+    "ekf_set_P": (_i32, [_vp, _dp, _i64]),
+    "ekf_get_P_block": (_i32, [_vp, _i64, _i64, _i64, _i64, _dp]),
+    "ekf_get_Q": (_i32, [_vp, _dp]),
+    "ekf_load_lowrank_state": (_i32, [_vp, _i64, _dp, _dp, _dp, _dp, _i64]),
+    "ekf_P_digest": (_i32, [_vp, _dp]),
+    "ekf_device_bytes": (_i32, [_vp, ctypes.POINTER(_i64)]),
+    "ekf_kernel_timing_enable": (_i32, [_vp, _i32, _i32]),
+    "ekf_kernel_timing_read": (_i32, [_vp, _i32, ctypes.POINTER(_i64), _dp]),
+    "ekf_downdate_algorithmic_bytes": (_i32, [_vp, ctypes.POINTER(_i64)]),
+}
+
+_LIB = None
+
+
+class EkfError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("libekfslam status %d: %s" % (status, message))
+        self.status = status
+
+
+def build():
+    """Compile libekfslam.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libekfslam.so is not built (%s); run __graft_entry__.build() or "
+                              "`make -C ekf_slam_amd/csrc` -- there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

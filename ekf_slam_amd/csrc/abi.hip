@@ -1,0 +1,620 @@
+// C ABI of libekfslam (include/ekfslam.h): handle, HBM buffers, launch sequencing, measure() dispatch.
+// No torch types, no exceptions across the boundary.  There is NO CPU fallback: without a HIP device
+// ekf_create fails with EKF_ERR_NO_DEVICE.
+#include "../../include/ekfslam.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "device_math.h"
+#include "kernels.h"
+#include "layout.h"
+
+struct KernelTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;              // events used since the last read
+};
+
+struct ekf_handle {
+    ekf_config cfg;
+    int64_t N = 0;         // landmarks in the state (host mirror; appends are host-initiated)
+    int64_t cap = 0;
+    int32_t T = 64;
+    int32_t storage = 0;
+    int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
+    DevState st;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // work list of owned lower-triangle tiles for the active tile rows
+    int2 *d_work = nullptr;
+    int64_t nwork = 0, work_rows = -1, work_cap = 0;
+    AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
+    double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
+    double *h_small = nullptr;   // pinned 32 doubles
+    KernelTimer timers[EKF_KERNEL_COUNT];
+    std::vector<void *> allocs;
+    int64_t bytes = 0;
+    int grid_cap = 0;
+    std::string err;
+};
+
+namespace {
+
+int32_t fail(ekf_handle *h, int32_t status, const char *what, hipError_t e = hipSuccess) {
+    if (h) {
+        h->err = what ? what : "";
+        if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); }
+    }
+    return status;
+}
+
+#define HIPCHK(h, call)                                                      \
+    do {                                                                     \
+        hipError_t e_ = (call);                                              \
+        if (e_ != hipSuccess) return fail((h), EKF_ERR_HIP, #call, e_);      \
+    } while (0)
+
+#define REQUIRE(h, cond, status, msg)                                        \
+    do { if (!(cond)) return fail((h), (status), (msg)); } while (0)
+
+template <typename Tp>
+hipError_t dalloc(ekf_handle *h, Tp **p, size_t count) {
+    void *q = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(Tp);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return e;
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) return e;
+    h->allocs.push_back(q);
+    h->bytes += (int64_t)bytes;
+    *p = (Tp *)q;
+    return hipSuccess;
+}
+
+inline int64_t n_mm(const ekf_handle *h) { return 2 * h->N; }
+inline size_t elt_size(const ekf_handle *h) { return h->storage == EKF_STORE_F64 ? 8 : 4; }
+
+int32_t use_device(ekf_handle *h) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return EKF_OK;
+}
+
+// (re)build the list of owned tiles for the active tile rows
+int32_t refresh_work(ekf_handle *h) {
+    const int64_t nt = ekf_tiles_for(n_mm(h), h->T);
+    if (nt == h->work_rows) return EKF_OK;
+    std::vector<int2> w;
+    w.reserve((size_t)h->st.tm.slots_for_rows(nt));
+    for (int64_t I = 0; I < nt; ++I)
+        for (int64_t J = 0; J <= I; ++J)
+            if (h->st.tm.mine(I, J)) w.push_back(make_int2((int)I, (int)J));
+    REQUIRE(h, (int64_t)w.size() <= h->work_cap, EKF_ERR_STATE, "work list overflow");
+    if (!w.empty()) {
+        HIPCHK(h, hipMemcpyAsync(h->d_work, w.data(), w.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));   // w is pageable and about to go out of scope
+    }
+    h->nwork = (int64_t)w.size();
+    h->work_rows = nt;
+    return EKF_OK;
+}
+
+struct TimedLaunch {
+    ekf_handle *h;
+    KernelTimer *t;
+    hipEvent_t stop = nullptr;
+    TimedLaunch(ekf_handle *h_, int which) : h(h_), t(&h_->timers[which]) {
+        if (!t->enabled) { t = nullptr; return; }
+        if (t->used + 2 > t->ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { t = nullptr; return; }
+            t->ev.push_back(a); t->ev.push_back(b);
+        }
+        hipEventRecord(t->ev[t->used], h->stream);
+        stop = t->ev[t->used + 1];
+        t->used += 2;
+    }
+    ~TimedLaunch() { if (t) hipEventRecord(stop, h->stream); }
+};
+
+void colmajor2(const double R[4], double &r00, double &r01, double &r10, double &r11) {
+    r00 = R[0]; r10 = R[1]; r01 = R[2]; r11 = R[3];
+}
+
+int32_t do_predict(ekf_handle *h, const double u[2]) {
+    PredictArgs a;
+    a.u0 = u[0]; a.u1 = u[1]; a.C = h->cfg.C; a.n_mm = n_mm(h); a.cur = h->cur;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_PREDICT);
+        HIPCHK(h, launch_predict(h->st, a, h->storage, h->stream));
+    }
+    h->cur ^= 1;
+    return EKF_OK;
+}
+
+int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature) {
+    REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
+    AppendArgs a;
+    a.u0 = u[0]; a.u1 = u[1];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.pos0 = pos[0]; a.pos1 = pos[1]; a.signature = signature; a.N = h->N; a.cur = h->cur;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_APPEND);
+        HIPCHK(h, launch_append(h->st, a, h->storage, h->stream));
+    }
+    h->N += 1;
+    return EKF_OK;
+}
+
+int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
+    int32_t rc = refresh_work(h);
+    if (rc) return rc;
+    CorrectArgs a;
+    a.z0 = z[0]; a.z1 = z[1];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_GATHER);
+        HIPCHK(h, launch_gather(h->st, a, h->storage, h->stream));
+    }
+    h->cur ^= 1;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
+        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->storage, h->grid_cap, h->stream));
+    }
+    return EKF_OK;
+}
+
+int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
+                     double *pos_cost, double *sig_cost) {
+    REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
+    AssocArgs a;
+    a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
+    a.N = h->N; a.cur = h->cur;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
+        HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_decision, h->storage,
+                                   h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
+    if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *is_new = h->h_decision->is_new;
+    *idx = h->h_decision->index;
+    return EKF_OK;
+}
+
+// landmark(find([landmark.index] == key)).loc  (key < 0: find([landmark.index]), i.e. all non-zero indices)
+int32_t lookup_loc(ekf_handle *h, const double *lm_index, const double *lm_loc, int64_t L, bool any_nonzero, double key,
+                   double loc[2]) {
+    int64_t hits = 0, at = -1;
+    for (int64_t i = 0; i < L; ++i) {
+        const bool m = any_nonzero ? (lm_index[i] != 0.0) : (lm_index[i] == key);
+        if (m) { ++hits; at = i; }
+    }
+    if (hits != 1) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "measure: landmark lookup matched %lld entries (the reference's append() call is "
+                 "only well-formed for exactly one)", (long long)hits);
+        return fail(h, EKF_ERR_LOOKUP, buf);
+    }
+    loc[0] = lm_loc[at];
+    loc[1] = lm_loc[L + at];
+    return EKF_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int32_t ekf_abi_version(void) { return EKF_ABI_VERSION; }
+
+const char *ekf_status_string(int32_t s) {
+    switch (s) {
+        case EKF_OK: return "ok";
+        case EKF_ERR_INVALID_ARG: return "invalid argument";
+        case EKF_ERR_NO_DEVICE: return "no HIP device";
+        case EKF_ERR_HIP: return "HIP runtime error";
+        case EKF_ERR_CAPACITY: return "landmark capacity exhausted";
+        case EKF_ERR_INDEX: return "landmark index outside the state";
+        case EKF_ERR_LOOKUP: return "landmark table lookup did not match exactly one entry";
+        case EKF_ERR_STATE: return "call not valid in the current state";
+        case EKF_ERR_COMM: return "multi-GPU exchange failed";
+        default: return "unknown status";
+    }
+}
+
+int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
+    if (!cfg || (mode != EKF_MODE_KNOWN && mode != EKF_MODE_UC)) return EKF_ERR_INVALID_ARG;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->C = 0.2;                                     // EKF_SLAM.m:12
+    cfg->Rc[0] = mode == EKF_MODE_KNOWN ? .01 : .1;   // EKF_SLAM.m:13 / EKF_SLAM_UC.m:13
+    cfg->Rc[1] = 5;
+    cfg->s_cost = .00000000001;                       // EKF_SLAM.m:14 / EKF_SLAM_UC.m:16
+    cfg->s_thresh = 1000000000;                       // EKF_SLAM.m:16 / EKF_SLAM_UC.m:16
+    cfg->w_pos = 0.0;                                 // Correspondence.m:75 is the live line
+    cfg->capacity_landmarks = 1024;
+    cfg->mode = mode;
+    cfg->storage = EKF_STORE_F64;
+    cfg->device = 0;
+    cfg->tile = 0;
+    cfg->rank = 0;
+    cfg->world = 1;
+    return EKF_OK;
+}
+
+int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
+    if (!cfg || !out) return EKF_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int32_t T = cfg->tile == 0 ? 64 : cfg->tile;
+    const int32_t world = cfg->world <= 0 ? 1 : cfg->world;
+    if (!(T == 16 || T == 32 || T == 64 || T == 128)) return EKF_ERR_INVALID_ARG;
+    if (cfg->capacity_landmarks < 1 || cfg->rank < 0 || cfg->rank >= world) return EKF_ERR_INVALID_ARG;
+    if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
+    if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
+        return EKF_ERR_NO_DEVICE;
+
+    ekf_handle *h = new (std::nothrow) ekf_handle();
+    if (!h) return EKF_ERR_INVALID_ARG;
+    h->cfg = *cfg;
+    h->cfg.world = world;
+    h->cfg.tile = T;
+    h->T = T;
+    h->cap = cfg->capacity_landmarks;
+    h->storage = cfg->storage;
+    *out = h;   // returned even on failure so the caller can read ekf_last_error, then ekf_destroy
+
+    HIPCHK(h, hipSetDevice(cfg->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+
+    const int64_t nt_cap = ekf_tiles_for(2 * h->cap, T);
+    const int64_t ldm = nt_cap * T;
+    h->st.ldm = ldm;
+    h->st.tm = ekf_make_tilemap(T, world, cfg->rank);
+    const int64_t slots = h->st.tm.slots_for_rows(nt_cap);
+    h->work_cap = slots;
+    for (int b = 0; b < 2; ++b) {
+        HIPCHK(h, dalloc(h, &h->st.x[b], (size_t)(3 + ldm)));
+        HIPCHK(h, dalloc(h, &h->st.prr[b], 16));
+        HIPCHK(h, dalloc(h, &h->st.strip[b], (size_t)(3 * ldm)));
+    }
+    {
+        char *tiles = nullptr;
+        HIPCHK(h, dalloc(h, &tiles, (size_t)slots * T * T * elt_size(h)));
+        h->st.tiles = tiles;
+    }
+    HIPCHK(h, dalloc(h, &h->st.s, (size_t)h->cap));
+    HIPCHK(h, dalloc(h, &h->st.Gi, (size_t)(2 * ldm)));
+    HIPCHK(h, dalloc(h, &h->st.Ki, (size_t)(2 * ldm)));
+    HIPCHK(h, dalloc(h, &h->st.small, 32));
+    HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
+    HIPCHK(h, dalloc(h, &h->d_partial, (size_t)((h->cap + kAssocBlock - 1) / kAssocBlock)));
+    HIPCHK(h, dalloc(h, &h->d_decision, 1));
+    HIPCHK(h, dalloc(h, &h->d_pos_cost, (size_t)h->cap));
+    HIPCHK(h, dalloc(h, &h->d_sig_cost, (size_t)h->cap));
+    HIPCHK(h, dalloc(h, &h->d_digest, 4));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_decision, sizeof(AssocDecision), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
+
+    // x = [0 0 0]; P = 0.1*eye(3)   (EKF_SLAM.m:28-31, EKF_SLAM_UC.m:29-32)
+    const double prr0[9] = { 0.1, 0, 0, 0, 0.1, 0, 0, 0, 0.1 };
+    HIPCHK(h, hipMemcpy(h->st.prr[0], prr0, sizeof prr0, hipMemcpyHostToDevice));
+    h->cur = 0;
+    h->N = 0;
+    const char *gc = getenv("EKF_DOWNDATE_GRID");
+    h->grid_cap = gc ? atoi(gc) : 0;
+    HIPCHK(h, hipDeviceSynchronize());
+    return EKF_OK;
+}
+
+int32_t ekf_destroy(ekf_handle *h) {
+    if (!h) return EKF_OK;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->h_decision) hipHostFree(h->h_decision);
+    if (h->h_small) hipHostFree(h->h_small);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return EKF_OK;
+}
+
+const char *ekf_last_error(const ekf_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int32_t ekf_set_stream(ekf_handle *h, void *hip_stream) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return EKF_OK;
+}
+
+int32_t ekf_sync(ekf_handle *h) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_predict(ekf_handle *h, const double u[2]) {
+    if (!h || !u) return fail(h, EKF_ERR_INVALID_ARG, "predict: null argument");
+    int32_t rc = use_device(h);
+    return rc ? rc : do_predict(h, u);
+}
+
+int32_t ekf_motion_model(const double *x, int64_t n, const double u[2], double *x_new, double *F) {
+    if (!x || !u || !x_new || n < 3) return EKF_ERR_INVALID_ARG;
+    const double th = x[2];
+    for (int64_t i = 0; i < n; ++i) x_new[i] = x[i];
+    x_new[0] = x[0] + u[0] * ekfm::cosd(th + u[1]);           // EKF_SLAM.m:58-60
+    x_new[1] = x[1] + u[0] * ekfm::sind(th + u[1]);
+    x_new[2] = th + u[1];
+    if (F) {
+        for (int64_t i = 0; i < n * n; ++i) F[i] = 0.0;
+        for (int64_t i = 0; i < n; ++i) F[i * n + i] = 1.0;  // eye(n)
+        F[2 * n + 0] = -1 * u[0] * ekfm::sind(th);           // F(1,3), column-major
+        F[2 * n + 1] = u[0] * ekfm::cosd(th);                // F(2,3)
+    }
+    return EKF_OK;
+}
+
+int32_t ekf_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature) {
+    if (!h || !u || !R || !pos) return fail(h, EKF_ERR_INVALID_ARG, "append: null argument");
+    int32_t rc = use_device(h);
+    return rc ? rc : do_append(h, u, R, pos, signature);
+}
+
+int32_t ekf_correct(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    if (!h || !z || !R) return fail(h, EKF_ERR_INVALID_ARG, "correct: null argument");
+    int32_t rc = use_device(h);
+    return rc ? rc : do_correct(h, z, R, idx);
+}
+
+int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
+                      double *pos_cost, double *sig_cost) {
+    if (!h || !z || !R || !is_new || !idx) return fail(h, EKF_ERR_INVALID_ARG, "associate: null argument");
+    int32_t rc = use_device(h);
+    return rc ? rc : do_associate(h, z, R, is_new, idx, pos_cost, sig_cost);
+}
+
+int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[2], const double *lm_index,
+                    const double *lm_loc, int64_t L) {
+    if (!h || !u || m < 0 || L < 0 || (m > 0 && !obs) || (L > 0 && (!lm_index || !lm_loc)))
+        return fail(h, EKF_ERR_INVALID_ARG, "measure: bad argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    for (int64_t ii = 0; ii < m; ++ii) {                                   // EKF_SLAM.m:107
+        const double z[3] = { obs[ii], obs[m + ii], obs[2 * m + ii] };
+        const double R[4] = { z[0] * h->cfg.Rc[0], 0.0, 0.0, z[1] * h->cfg.Rc[1] };   // :108
+        double loc[2];
+        if (h->N == 0) {                                                   // :110-111  length(x) < 4
+            rc = lookup_loc(h, lm_index, lm_loc, L, true, 0.0, loc);
+            if (rc) return rc;
+            rc = do_append(h, u, R, loc, 1.0);
+        } else if (h->cfg.mode == EKF_MODE_KNOWN) {
+            if (z[2] > (double)h->N) {                                     // :118-120
+                rc = lookup_loc(h, lm_index, lm_loc, L, false, z[2], loc);
+                if (rc) return rc;
+                rc = do_append(h, u, R, loc, z[2]);
+            } else {
+                rc = do_correct(h, z, R, ii);                              // :123  idx = ii
+            }
+        } else {
+            int32_t is_new = 0;
+            int64_t idx = 0;
+            rc = do_associate(h, z, R, &is_new, &idx, nullptr, nullptr);   // EKF_SLAM_UC.m:119
+            if (rc) return rc;
+            if (is_new) {                                                  // EKF_SLAM_UC.m:121-123
+                rc = lookup_loc(h, lm_index, lm_loc, L, false, (double)(idx + 1), loc);
+                if (rc) return rc;
+                rc = do_append(h, u, R, loc, (double)(idx + 1));
+            } else {
+                rc = do_correct(h, z, R, idx);
+            }
+        }
+        if (rc) return rc;
+    }
+    return EKF_OK;
+}
+
+int32_t ekf_num_landmarks(ekf_handle *h, int64_t *N) {
+    if (!h || !N) return fail(h, EKF_ERR_INVALID_ARG, "num_landmarks: null argument");
+    *N = h->N;
+    return EKF_OK;
+}
+
+int32_t ekf_get_x(ekf_handle *h, double *x) {
+    if (!h || !x) return fail(h, EKF_ERR_INVALID_ARG, "get_x: null argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(x, h->st.x[h->cur], (size_t)(3 + n_mm(h)) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
+    if (!h || !x) return fail(h, EKF_ERR_INVALID_ARG, "set_x: null argument");
+    REQUIRE(h, n >= 3 && (n - 3) % 2 == 0 && (n - 3) / 2 <= h->cap, EKF_ERR_INVALID_ARG, "set_x: bad length");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    h->N = (n - 3) / 2;
+    HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_get_s(ekf_handle *h, double *s) {
+    if (!h || (!s && h->N > 0)) return fail(h, EKF_ERR_INVALID_ARG, "get_s: null argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    if (h->N > 0) HIPCHK(h, hipMemcpyAsync(s, h->st.s, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
+    if (!h || (!s && N > 0)) return fail(h, EKF_ERR_INVALID_ARG, "set_s: null argument");
+    REQUIRE(h, N == h->N, EKF_ERR_INVALID_ARG, "set_s: length must equal the number of landmarks (set x first)");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    if (N > 0) HIPCHK(h, hipMemcpyAsync(h->st.s, s, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_get_P(ekf_handle *h, double *P) {
+    if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "get_P: null argument");
+    REQUIRE(h, h->cfg.world == 1, EKF_ERR_STATE, "get_P: a shard holds only its own tiles; use ekf_get_P_block per shard");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = 3 + n_mm(h);
+    double *dense = nullptr;
+    HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
+    hipError_t e = launch_unpack_dense(h->st, h->cur, n_mm(h), dense, h->storage, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(P, dense, (size_t)(n * n) * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(dense);
+    if (e != hipSuccess) return fail(h, EKF_ERR_HIP, "get_P", e);
+    return EKF_OK;
+}
+
+int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
+    if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "set_P: null argument");
+    REQUIRE(h, n == 3 + n_mm(h), EKF_ERR_INVALID_ARG, "set_P: n must equal length(x) (set x first)");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    double *dense = nullptr;
+    HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
+    hipError_t e = hipMemcpyAsync(dense, P, (size_t)(n * n) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_pack_dense(h->st, h->cur, n_mm(h), dense, h->storage, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(dense);
+    if (e != hipSuccess) return fail(h, EKF_ERR_HIP, "set_P", e);
+    return EKF_OK;
+}
+
+int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64_t nc, double *out) {
+    if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "get_P_block: null argument");
+    const int64_t n = 3 + n_mm(h);
+    REQUIRE(h, r0 >= 0 && c0 >= 0 && nr >= 1 && nc >= 1 && r0 + nr <= n && c0 + nc <= n, EKF_ERR_INVALID_ARG,
+            "get_P_block: block outside P");
+    REQUIRE(h, h->cfg.world == 1, EKF_ERR_STATE, "get_P_block: not available on a shard yet");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    double *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, (size_t)(nr * nc) * 8));
+    hipError_t e = launch_get_block(h->st, h->cur, r0, c0, nr, nc, d, h->storage, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, (size_t)(nr * nc) * 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(h, EKF_ERR_HIP, "get_P_block", e);
+    return EKF_OK;
+}
+
+int32_t ekf_get_Q(ekf_handle *h, double Q[9]) {
+    if (!h || !Q) return fail(h, EKF_ERR_INVALID_ARG, "get_Q: null argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->st.small, 32 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Q[c * 3 + r] = h->h_small[12 + 3 * r + c];
+    return EKF_OK;
+}
+
+int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const double *s, const double *d,
+                               const double *U, int64_t k) {
+    if (!h || !x || !s || !d || !U) return fail(h, EKF_ERR_INVALID_ARG, "load_lowrank_state: null argument");
+    REQUIRE(h, N >= 0 && N <= h->cap && k >= 1, EKF_ERR_INVALID_ARG, "load_lowrank_state: bad N or k");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    const int64_t n = 3 + 2 * N;
+    h->N = N;
+    rc = refresh_work(h);
+    if (rc) return rc;
+    double *dd = nullptr, *dU = nullptr;
+    HIPCHK(h, hipMalloc((void **)&dd, (size_t)n * 8));
+    hipError_t e = hipMalloc((void **)&dU, (size_t)(n * k) * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(dd, d, (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dU, U, (size_t)(n * k) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && N > 0) e = hipMemcpyAsync(h->st.s, s, (size_t)N * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_lowrank(h->st, h->cur, 2 * N, h->d_work, h->nwork, dd, dU, k, h->storage, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(dd);
+    if (dU) hipFree(dU);
+    if (e != hipSuccess) return fail(h, EKF_ERR_HIP, "load_lowrank_state", e);
+    return EKF_OK;
+}
+
+int32_t ekf_P_digest(ekf_handle *h, double out[3]) {
+    if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "P_digest: null argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    rc = refresh_work(h);
+    if (rc) return rc;
+    HIPCHK(h, launch_digest(h->st, h->cur, n_mm(h), h->d_work, h->nwork, h->d_digest, h->storage, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->h_small, h->d_digest, 3 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out[0] = h->h_small[0]; out[1] = h->h_small[1]; out[2] = h->h_small[2];
+    return EKF_OK;
+}
+
+int32_t ekf_device_bytes(ekf_handle *h, int64_t *bytes) {
+    if (!h || !bytes) return fail(h, EKF_ERR_INVALID_ARG, "device_bytes: null argument");
+    *bytes = h->bytes;
+    return EKF_OK;
+}
+
+int32_t ekf_kernel_timing_enable(ekf_handle *h, int32_t which, int32_t on) {
+    if (!h || which < 0 || which >= EKF_KERNEL_COUNT) return fail(h, EKF_ERR_INVALID_ARG, "kernel_timing_enable: bad kernel id");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->timers[which].enabled = on != 0;
+    h->timers[which].used = 0;
+    return EKF_OK;
+}
+
+int32_t ekf_kernel_timing_read(ekf_handle *h, int32_t which, int64_t *launches, double *total_ms) {
+    if (!h || which < 0 || which >= EKF_KERNEL_COUNT || !launches || !total_ms)
+        return fail(h, EKF_ERR_INVALID_ARG, "kernel_timing_read: bad argument");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    KernelTimer &t = h->timers[which];
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < t.used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+        tot += ms;
+    }
+    *launches = (int64_t)(t.used / 2);
+    *total_ms = tot;
+    t.used = 0;
+    return EKF_OK;
+}
+
+int32_t ekf_downdate_algorithmic_bytes(ekf_handle *h, int64_t *bytes) {
+    if (!h || !bytes) return fail(h, EKF_ERR_INVALID_ARG, "downdate_algorithmic_bytes: null argument");
+    const int64_t n = 3 + n_mm(h);
+    *bytes = (int64_t)elt_size(h) * n * (n + 1);
+    return EKF_OK;
+}
+
+}  // extern "C"

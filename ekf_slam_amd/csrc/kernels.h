@@ -1,0 +1,82 @@
+// Host-side launch interface of the gfx950 kernels (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "layout.h"
+
+// Device-resident filter state.  Passed BY VALUE to every kernel.
+//   x / prr / strip are double-buffered: every kernel reads buffer `cur` and writes a complete buffer
+//   `cur ^ 1`, so no workgroup ever reads a value another workgroup of the same launch overwrites.
+struct DevState {
+    double *x[2];      // state vector, 3 + ldm
+    double *prr[2];    // P(1:3,1:3), row-major 3x3
+    double *strip[2];  // P(1:3, 4:end): 3 rows of ldm
+    void   *tiles;     // local tile store of the landmark block (double or float)
+    double *s;         // signatures, cap
+    double *Gi;        // 2*ldm: G = H_s P(S,:) over landmark columns, interleaved (G(1,c), G(2,c))
+    double *Ki;        // 2*ldm: K rows over landmark rows, interleaved (K(r,1), K(r,2))
+    double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
+    int64_t ldm;       // strip leading dimension = landmark-block capacity rounded up to T
+    TileMap tm;
+};
+
+struct CorrectArgs {
+    double z0, z1;            // [range, bearing_deg]
+    double R00, R01, R10, R11;
+    int64_t j;                // landmark-block row of the corrected landmark (2*idx)
+    int64_t n_mm;             // active landmark-block size (2N)
+    int32_t cur;
+};
+
+struct PredictArgs {
+    double u0, u1, C;
+    int64_t n_mm;
+    int32_t cur;
+};
+
+struct AppendArgs {
+    double u0, u1;
+    double R00, R01, R10, R11;
+    double pos0, pos1, signature;
+    int64_t N;                // landmarks before the append
+    int32_t cur;
+};
+
+struct AssocArgs {
+    double z0, z1, z2;
+    double R00, R01, R10, R11;
+    double s_cost, s_thresh, w_pos;
+    int64_t N;
+    int32_t cur;
+};
+
+struct AssocDecision {        // written by the device, read back by the host
+    int64_t index;            // 0-based; == N for a new landmark
+    int32_t is_new;
+    int32_t pad;
+    double  min_ll;
+};
+
+constexpr int kAssocBlock = 256;
+
+hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s);
+hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, hipStream_t s);
+// tiles -= K G over the work list (I,J pairs, device array) of `nwork` owned lower-triangle tiles
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int storage, int grid_cap,
+                           hipStream_t s);
+// pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
+hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
+                            AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s);
+// dense (column-major, n x n, device) <-> tiled
+hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s);
+hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s);
+hipError_t launch_get_block(const DevState &st, int cur, int64_t r0, int64_t c0, int64_t nr, int64_t nc,
+                            double *out, int storage, hipStream_t s);
+// P = diag(d) + U U' (d: n, U: n x k column-major, device)
+hipError_t launch_lowrank(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, const double *d,
+                          const double *U, int64_t k, int storage, hipStream_t s);
+// out[3] (device, zeroed by the callee): trace, sum and sum of squares over the lower triangle
+hipError_t launch_digest(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, double *out,
+                         int storage, hipStream_t s);

@@ -1,0 +1,625 @@
+// gfx950 (MI355X / CDNA4) kernels of the EKF-SLAM update engine.
+//
+// Every kernel here is HBM- or latency-bound (AI of the rank-2 downdate is 0.25 flop/B in f64); none is
+// GEMM-shaped, so the rules that matter are: 16-byte-per-lane coalesced accesses on whole 64-lane
+// wavefronts, many independent loads in flight per lane, >> 256 workgroups per launch, nothing re-read
+// from HBM that can be kept in registers, no host synchronisation between launches.
+//
+// Reference expressions realised (file:line in the reference tree):
+//   k_predict    P = F*P*F' + Q, x = f(x,u), wrapTo360          EKF_SLAM.m:40-51,56-65
+//   k_append     state/covariance growth                         EKF_SLAM.m:67-98 (append.m:1-27)
+//   k_gather     z_k, H_k, phi_k, K, x += K nu                   EKF_SLAM.m:125-144
+//   k_downdate   P = (I - K H_k) P  ==  P - K (H_k P)            EKF_SLAM.m:145
+//   k_associate  per-landmark phi_k, Mahalanobis + signature     Correspondence.m:49-87
+#include "kernels.h"
+
+#include "device_math.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------------
+// element access
+// ---------------------------------------------------------------------------------------------------
+// canonical (lower-triangle) element (r,c) of the landmark block; r,c are landmark-block indices
+template <typename TS>
+__device__ __forceinline__ double pmm_low(const TS *__restrict__ tiles, const TileMap &tm, int64_t r, int64_t c) {
+    if (r < c) { const int64_t t = r; r = c; c = t; }
+    const int64_t I = r >> tm.shift, J = c >> tm.shift;
+    const int64_t m = tm.T - 1;
+    return (double)tiles[tm.tile_offset(I, J) + ((r & m) << tm.shift) + (c & m)];
+}
+
+template <typename TS>
+__device__ __forceinline__ void pmm_low_store(TS *__restrict__ tiles, const TileMap &tm, int64_t r, int64_t c, double v) {
+    if (r < c) { const int64_t t = r; r = c; c = t; }
+    const int64_t I = r >> tm.shift, J = c >> tm.shift;
+    const int64_t m = tm.T - 1;
+    tiles[tm.tile_offset(I, J) + ((r & m) << tm.shift) + (c & m)] = (TS)v;
+}
+
+// full-state element P(r,c), r,c in [0, 3+n_mm)
+template <typename TS>
+__device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, int64_t c) {
+    if (r < 3 && c < 3) return st.prr[cur][3 * r + c];
+    if (r < 3) return st.strip[cur][r * st.ldm + (c - 3)];
+    if (c < 3) return st.strip[cur][c * st.ldm + (r - 3)];
+    return pmm_low<TS>((const TS *)st.tiles, st.tm, r - 3, c - 3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// predict: one thread per strip column; thread 0 also owns the pose, Prr and Q
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_predict(DevState st, PredictArgs a) {
+    const int cur = a.cur, nxt = cur ^ 1;
+    const double *__restrict__ x = st.x[cur];
+    double *__restrict__ xn = st.x[nxt];
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double th = x[2];
+    // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
+    const double fa = -1 * a.u0 * ekfm::sind(th);
+    const double fb = a.u0 * ekfm::cosd(th);
+    if (c < a.n_mm) {
+        const double *__restrict__ s = st.strip[cur];
+        double *__restrict__ sn = st.strip[nxt];
+        const double s0 = s[c], s1 = s[st.ldm + c], s2 = s[2 * st.ldm + c];
+        sn[c] = s0 + fa * s2;              // (F*P)(1,:) = P(1,:) + F(1,3) P(3,:)
+        sn[st.ldm + c] = s1 + fb * s2;
+        sn[2 * st.ldm + c] = s2;
+        xn[3 + c] = x[3 + c];
+    }
+    if (c == 0) {
+        const double W[3] = { a.u0 * ekfm::cosd(th), a.u0 * ekfm::sind(th), a.u1 };   // EKF_SLAM.m:42
+        double Q[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Q[3 * i + j] = (W[i] * a.C) * W[j];           // EKF_SLAM.m:44
+        double M[9];
+        for (int i = 0; i < 9; ++i) M[i] = st.prr[cur][i];
+        for (int j = 0; j < 3; ++j) { const double p2 = M[6 + j]; M[j] += fa * p2; M[3 + j] += fb * p2; }      // F*P
+        for (int i = 0; i < 3; ++i) { const double p2 = M[3 * i + 2]; M[3 * i] += fa * p2; M[3 * i + 1] += fb * p2; }  // *F'
+        for (int i = 0; i < 9; ++i) { st.prr[nxt][i] = M[i] + Q[i]; st.small[12 + i] = Q[i]; }
+        xn[0] = x[0] + a.u0 * ekfm::cosd(th + a.u1);                                   // EKF_SLAM.m:58-60
+        xn[1] = x[1] + a.u0 * ekfm::sind(th + a.u1);
+        xn[2] = ekfm::wrapTo360(th + a.u1);                                            // EKF_SLAM.m:50
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// append: in place on buffer `cur` (only new slots are written)
+// ---------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a) {
+    const int cur = a.cur;
+    double *__restrict__ x = st.x[cur];
+    double *__restrict__ s = st.strip[cur];
+    const double *__restrict__ prr = st.prr[cur];
+    TS *__restrict__ tiles = (TS *)st.tiles;
+    const int64_t n_mm = 2 * a.N;          // old landmark-block size; new rows are n_mm, n_mm + 1
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const double th = x[2];                // post-predict heading (EKF_SLAM.m:84-85)
+    const double jxr[2][3] = { { 1, 0, -a.u0 * ekfm::sind(th) }, { 0, 1, a.u0 * ekfm::cosd(th) } };
+    if (c < n_mm) {
+        // F: P(new, lm) = jxr * P(lm, 1:3)'   (EKF_SLAM.m:95); the column strip equals the row strip here
+        const double s0 = s[c], s1 = s[st.ldm + c], s2 = s[2 * st.ldm + c];
+        for (int i = 0; i < 2; ++i) {
+            const double v = jxr[i][0] * s0 + jxr[i][1] * s1 + jxr[i][2] * s2;
+            if (st.tm.mine((n_mm + i) >> st.tm.shift, c >> st.tm.shift))
+                pmm_low_store<TS>(tiles, st.tm, n_mm + i, c, v);
+        }
+    }
+    if (c == 0) {
+        x[3 + n_mm] = a.pos0;                                                         // EKF_SLAM.m:79
+        x[3 + n_mm + 1] = a.pos1;
+        st.s[a.N] = a.signature;                                                      // EKF_SLAM.m:70
+        const double jz[2][2] = { { ekfm::cosd(a.u1), -a.u0 * ekfm::sind(a.u1) },
+                                  { ekfm::sind(a.u1),  a.u0 * ekfm::cosd(a.u1) } };   // EKF_SLAM.m:87-88
+        const double R[2][2] = { { a.R00, a.R01 }, { a.R10, a.R11 } };
+        double t[2][3], c1[2][2], t2[2][2], c2[2][2];
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) {
+            double acc = 0; for (int k = 0; k < 3; ++k) acc += jxr[i][k] * prr[3 * k + j]; t[i][j] = acc; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+            double acc = 0; for (int k = 0; k < 3; ++k) acc += t[i][k] * jxr[j][k]; c1[i][j] = acc; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+            double acc = 0; for (int k = 0; k < 2; ++k) acc += jz[i][k] * R[k][j]; t2[i][j] = acc; }
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
+            double acc = 0; for (int k = 0; k < 2; ++k) acc += t2[i][k] * jz[j][k]; c2[i][j] = acc; }
+        // C: jxr*Prr*jxr' + jz*R*jz' (EKF_SLAM.m:91); only the lower triangle of the 2x2 block is canonical
+        if (st.tm.mine(n_mm >> st.tm.shift, n_mm >> st.tm.shift)) {
+            pmm_low_store<TS>(tiles, st.tm, n_mm, n_mm, c1[0][0] + c2[0][0]);
+            pmm_low_store<TS>(tiles, st.tm, n_mm + 1, n_mm, c1[1][0] + c2[1][0]);
+            pmm_low_store<TS>(tiles, st.tm, n_mm + 1, n_mm + 1, c1[1][1] + c2[1][1]);
+        }
+        // I: P(1:3,new) = Prr*jxr' (EKF_SLAM.m:92); H is its mirror and shares the strip storage
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) {
+            double acc = 0; for (int k = 0; k < 3; ++k) acc += prr[3 * i + k] * jxr[j][k];
+            s[i * st.ldm + n_mm + j] = acc; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gather + solve.  One thread per landmark column c:
+//     G(:,c) = H_s * P(S,c),  K(c,:) = G(:,c)' * inv(phi),  x(c) += K(c,:) nu,  strip(:,c) -= K_r G(:,c)
+// The 5x5 sub-block P(S,S) that phi needs is fetched by every workgroup (19 doubles, L2-resident), so
+// there is no inter-workgroup dependency and the whole correction is two launches.
+// ---------------------------------------------------------------------------------------------------
+struct SmallSolve {
+    double Hs[2][5];
+    double Phi[4];     // inv(phi), row-major
+    double nu[2];
+    double Kr[3][2];
+    double Gr[2][3];
+};
+
+// pss: 0..8 Prr row-major; 9+2t+b = P(t, j+b), t<3, b<2; 15+2t+b = canonical P(j+t, j+b); 19..21 x_r; 22..23 x_j
+__device__ inline void solve_small(const double *pss, double z0, double z1, double R00, double R01, double R10,
+                                   double R11, SmallSolve &o) {
+    const double d0 = pss[22] - pss[19], d1 = pss[23] - pss[20];                       // EKF_SLAM.m:125-126
+    const double q = d0 * d0 + d1 * d1, sq = sqrt(q);                                  // :127
+    const double zhat0 = sq;
+    const double zhat1 = ekfm::wrapTo360(ekfm::atan2d(d1, d0) - pss[21]);              // :130
+    const double iq = 1 / q;
+    const double e[2][5] = { { -sq * d0, -sq * d1, 0, sq * d0, sq * d1 }, { d1, -d0, -q, -d1, d0 } };
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 5; ++b) o.Hs[a][b] = iq * e[a][b]; // :137-138
+    double GS[2][5];
+    for (int a = 0; a < 2; ++a) {
+        for (int b = 0; b < 3; ++b) {      // robot columns: P(j+t, b) is stored as strip(b, j+t)
+            double acc = 0;
+            for (int t = 0; t < 3; ++t) acc += o.Hs[a][t] * pss[3 * t + b];
+            for (int t = 0; t < 2; ++t) acc += o.Hs[a][3 + t] * pss[9 + 2 * b + t];
+            GS[a][b] = acc; o.Gr[a][b] = acc;
+        }
+        for (int b = 0; b < 2; ++b) {      // columns j, j+1
+            double acc = 0;
+            for (int t = 0; t < 3; ++t) acc += o.Hs[a][t] * pss[9 + 2 * t + b];
+            for (int t = 0; t < 2; ++t) acc += o.Hs[a][3 + t] * pss[15 + 2 * t + b];
+            GS[a][3 + b] = acc;
+        }
+    }
+    const double R[2][2] = { { R00, R01 }, { R10, R11 } };
+    double phi[4];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {                          // :141
+        double acc = 0; for (int t = 0; t < 5; ++t) acc += GS[a][t] * o.Hs[b][t];
+        phi[2 * a + b] = acc + R[a][b]; }
+    ekfm::inv2(phi, o.Phi);                                                            // :143 phi_k^-1
+    o.nu[0] = z0 - zhat0;                                                              // :144 (bearing NOT wrapped)
+    o.nu[1] = z1 - zhat1;
+    for (int b = 0; b < 3; ++b) for (int cc = 0; cc < 2; ++cc)
+        o.Kr[b][cc] = o.Gr[0][b] * o.Phi[cc] + o.Gr[1][b] * o.Phi[2 + cc];
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a) {
+    __shared__ double pss[24];
+    __shared__ SmallSolve sol;
+    const int tid = threadIdx.x;
+    const int cur = a.cur, nxt = cur ^ 1;
+    const double *__restrict__ x = st.x[cur];
+    const double *__restrict__ strip = st.strip[cur];
+    const TS *__restrict__ tiles = (const TS *)st.tiles;
+    const int64_t j = a.j, ldm = st.ldm;
+
+    if (tid < 9) pss[tid] = st.prr[cur][tid];
+    else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
+    else if (tid < 19) { const int t = (tid - 15) >> 1, b = (tid - 15) & 1; pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b); }
+    else if (tid < 22) pss[tid] = x[tid - 19];
+    else if (tid < 24) pss[tid] = x[3 + j + (tid - 22)];
+    __syncthreads();
+    if (tid == 0) solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
+    __syncthreads();
+
+    const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
+    const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
+    if (c < a.n_mm) {
+        // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part right)
+        const double m0 = pmm_low<TS>(tiles, st.tm, j, c);
+        const double m1 = pmm_low<TS>(tiles, st.tm, j + 1, c);
+        const double s0 = strip[c], s1 = strip[ldm + c], s2 = strip[2 * ldm + c];
+        double g[2];
+        for (int r = 0; r < 2; ++r)
+            g[r] = sol.Hs[r][0] * s0 + sol.Hs[r][1] * s1 + sol.Hs[r][2] * s2 + sol.Hs[r][3] * m0 + sol.Hs[r][4] * m1;
+        const double k0 = g[0] * sol.Phi[0] + g[1] * sol.Phi[2];
+        const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
+        reinterpret_cast<double2 *>(st.Gi)[c] = make_double2(g[0], g[1]);
+        reinterpret_cast<double2 *>(st.Ki)[c] = make_double2(k0, k1);
+        st.x[nxt][3 + c] = x[3 + c] + (k0 * sol.nu[0] + k1 * sol.nu[1]);
+        double *__restrict__ sn = st.strip[nxt];
+        sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
+        sn[ldm + c] = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
+        sn[2 * ldm + c] = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
+    } else if (c < pad_end) {
+        // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
+        reinterpret_cast<double2 *>(st.Gi)[c] = make_double2(0.0, 0.0);
+        reinterpret_cast<double2 *>(st.Ki)[c] = make_double2(0.0, 0.0);
+    }
+    if (c == 0) {
+        for (int b = 0; b < 3; ++b)
+            st.x[nxt][b] = x[b] + (sol.Kr[b][0] * sol.nu[0] + sol.Kr[b][1] * sol.nu[1]);   // x(3) NOT re-wrapped
+        for (int r = 0; r < 3; ++r) for (int b = 0; b < 3; ++b)
+            st.prr[nxt][3 * r + b] = st.prr[cur][3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
+        for (int r = 0; r < 2; ++r) for (int b = 0; b < 3; ++b) st.small[3 * r + b] = sol.Gr[r][b];
+        for (int b = 0; b < 3; ++b) for (int r = 0; r < 2; ++r) st.small[6 + 2 * b + r] = sol.Kr[b][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// rank-2 downdate of the landmark block:  tile(I,J)[r][c] -= K(I*T+r,:) . G(:,J*T+c)
+//
+// The HBM-bound kernel.  Every unique entry of P is read once and written once (w*n*(n+1) bytes per
+// launch); K and G (2 x n each) stay in L2.  A 256-thread workgroup walks owned tiles from a work list;
+// inside a tile each lane owns one 16-byte column pair and strides over the rows, so each wavefront
+// load/store instruction moves 1 KiB of contiguous tile memory, and the lane's four G values stay in
+// registers for the whole tile.
+// ---------------------------------------------------------------------------------------------------
+template <typename TS> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <typename TS, int T>
+__global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, const int2 *__restrict__ work,
+                                                     int64_t nwork, const double *__restrict__ Ki,
+                                                     const double *__restrict__ Gi, TileMap tm) {
+    using V2 = typename Vec2<TS>::type;
+    constexpr int kPairsPerRow = T / 2;
+    constexpr int kRowsPerPass = kBlock / kPairsPerRow;
+    constexpr int kPasses = (T + kRowsPerPass - 1) / kRowsPerPass;
+    constexpr int kUnroll = kPasses < 8 ? kPasses : 8;
+    const int tid = threadIdx.x;
+    const int cp = tid % kPairsPerRow;       // column pair inside the tile
+    const int r0 = tid / kPairsPerRow;       // first row of this lane
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int2 ij = work[w];
+        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y);
+        const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gi) + ((int64_t)ij.y * T + 2 * cp);
+        const double2 ga = g2[0], gb = g2[1];                      // (G1,G2) at columns 2cp and 2cp+1
+        const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Ki) + (int64_t)ij.x * T;
+#pragma unroll 1
+        for (int p0 = 0; p0 < kPasses; p0 += kUnroll) {
+            V2 v[kUnroll];
+            double2 k[kUnroll];
+#pragma unroll
+            for (int p = 0; p < kUnroll; ++p) {
+                const int r = r0 + (p0 + p) * kRowsPerPass;
+                if (kRowsPerPass * kPasses == T || r < T) {
+                    v[p] = *reinterpret_cast<const V2 *>(tp + r * T + 2 * cp);
+                    k[p] = k2[r];
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < kUnroll; ++p) {
+                const int r = r0 + (p0 + p) * kRowsPerPass;
+                if (kRowsPerPass * kPasses == T || r < T) {
+                    V2 o;
+                    o.x = (TS)((double)v[p].x - (k[p].x * ga.x + k[p].y * ga.y));
+                    o.y = (TS)((double)v[p].y - (k[p].x * gb.x + k[p].y * gb.y));
+                    *reinterpret_cast<V2 *>(tp + r * T + 2 * cp) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// association (Correspondence.m:49-87): one thread per landmark, block arg-min, then a one-block finish
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool assoc_better(double la, int64_t ia, double lb, int64_t ib) {
+    // strict '<' on the likelihood, first (lowest) index wins ties (Correspondence.m:81)
+    return la < lb || (la == lb && ia < ib);
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
+                                                           double *__restrict__ sig_cost,
+                                                           AssocDecision *__restrict__ partial) {
+    __shared__ double sh_ll[kAssocBlock];
+    __shared__ int64_t sh_ix[kAssocBlock];
+    const int tid = threadIdx.x;
+    const int cur = a.cur;
+    const int64_t k = (int64_t)blockIdx.x * kAssocBlock + tid;
+    double ll = INFINITY;
+    int64_t ix = INT64_MAX;
+    if (k < a.N) {
+        const double *__restrict__ x = st.x[cur];
+        const double *__restrict__ strip = st.strip[cur];
+        const TS *__restrict__ tiles = (const TS *)st.tiles;
+        const int64_t j = 2 * k;
+        double pss[24];
+        for (int i = 0; i < 9; ++i) pss[i] = st.prr[cur][i];
+        for (int t = 0; t < 3; ++t) for (int b = 0; b < 2; ++b) pss[9 + 2 * t + b] = strip[t * st.ldm + j + b];
+        for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b) pss[15 + 2 * t + b] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
+        for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
+        pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
+        SmallSolve sol;
+        solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
+        const double n0 = sol.nu[0], n1 = sol.nu[1];
+        const double pc = (n0 * sol.Phi[0] + n1 * sol.Phi[2]) * n0 + (n0 * sol.Phi[1] + n1 * sol.Phi[3]) * n1;  // :69
+        const double d = a.z2 - st.s[k];
+        const double sc = d * (1.0 / a.s_cost) * d;                                                          // :71
+        if (pos_cost) pos_cost[k] = pc;
+        if (sig_cost) sig_cost[k] = sc;
+        const double like = (a.w_pos != 0.0) ? (a.w_pos * pc + sc) : sc;                                      // :74-75
+        if (like <= a.s_thresh) { ll = like; ix = k; }                                                       // :78
+    }
+    sh_ll[tid] = ll; sh_ix[tid] = ix;
+    __syncthreads();
+    for (int s = kAssocBlock / 2; s > 0; s >>= 1) {
+        if (tid < s && assoc_better(sh_ll[tid + s], sh_ix[tid + s], sh_ll[tid], sh_ix[tid])) {
+            sh_ll[tid] = sh_ll[tid + s]; sh_ix[tid] = sh_ix[tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { partial[blockIdx.x].min_ll = sh_ll[0]; partial[blockIdx.x].index = sh_ix[0]; }
+}
+
+__global__ __launch_bounds__(kAssocBlock) void k_associate_finish(const AssocDecision *__restrict__ partial, int64_t nparts,
+                                                                  int64_t N, AssocDecision *__restrict__ decision) {
+    __shared__ double sh_ll[kAssocBlock];
+    __shared__ int64_t sh_ix[kAssocBlock];
+    const int tid = threadIdx.x;
+    double ll = INFINITY;
+    int64_t ix = INT64_MAX;
+    for (int64_t i = tid; i < nparts; i += kAssocBlock)
+        if (assoc_better(partial[i].min_ll, partial[i].index, ll, ix)) { ll = partial[i].min_ll; ix = partial[i].index; }
+    sh_ll[tid] = ll; sh_ix[tid] = ix;
+    __syncthreads();
+    for (int s = kAssocBlock / 2; s > 0; s >>= 1) {
+        if (tid < s && assoc_better(sh_ll[tid + s], sh_ix[tid + s], sh_ll[tid], sh_ix[tid])) {
+            sh_ll[tid] = sh_ll[tid + s]; sh_ix[tid] = sh_ix[tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool found = sh_ix[0] != INT64_MAX;     // something passed the threshold (min_ll starts at Inf, :43)
+        decision->is_new = found ? 0 : 1;
+        decision->index = found ? sh_ix[0] : N;       // default index = numOfLandmarks + 1 (:40), 0-based here
+        decision->min_ll = sh_ll[0];
+        decision->pad = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dense <-> tiled, block reads, low-rank bulk load, digests
+// ---------------------------------------------------------------------------------------------------
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_unpack_dense(DevState st, int cur, int64_t n, double *__restrict__ dense) {
+    // column-major output; consecutive threads walk a column (consecutive rows)
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n * n) return;
+    const int64_t c = e / n, r = e - c * n;
+    dense[e] = p_at<TS>(st, cur, r, c);
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_pack_dense(DevState st, int cur, int64_t n, const double *__restrict__ dense) {
+    // one thread per element of the lower triangle (r >= c) of the column-major input
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n * n) return;
+    const int64_t c = e / n, r = e - c * n;
+    if (r < c) return;
+    const double v = dense[e];
+    if (r < 3) { st.prr[cur][3 * r + c] = v; st.prr[cur][3 * c + r] = v; return; }
+    if (c < 3) { st.strip[cur][c * st.ldm + (r - 3)] = v; return; }
+    const int64_t rm = r - 3, cm = c - 3;
+    if (st.tm.mine(rm >> st.tm.shift, cm >> st.tm.shift)) pmm_low_store<TS>((TS *)st.tiles, st.tm, rm, cm, v);
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_get_block(DevState st, int cur, int64_t r0, int64_t c0, int64_t nr, int64_t nc,
+                                                      double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= nr * nc) return;
+    const int64_t c = e / nr, r = e - c * nr;
+    out[e] = p_at<TS>(st, cur, r0 + r, c0 + c);
+}
+
+// P = diag(d) + U U'.  Grid: x over (row, column-chunk) of the lower triangle in tile units is not needed
+// here (one-off bulk load): one thread per lower-triangle element of the padded tile grid.
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_lowrank_tiles(DevState st, int64_t n_mm, const int2 *__restrict__ work,
+                                                          int64_t nwork, const double *__restrict__ d,
+                                                          const double *__restrict__ U, int64_t k) {
+    const int T = st.tm.T;
+    const int64_t n = n_mm + 3;
+    TS *__restrict__ tiles = (TS *)st.tiles;
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int2 ij = work[w];
+        TS *__restrict__ tp = tiles + st.tm.tile_offset(ij.x, ij.y);
+        for (int e = threadIdx.x; e < T * T; e += kBlock) {
+            const int rr = e >> st.tm.shift, cc = e & (T - 1);
+            const int64_t r = (int64_t)ij.x * T + rr, c = (int64_t)ij.y * T + cc;
+            double v = 0.0;
+            if (r < n_mm && c < n_mm) {
+                for (int64_t q = 0; q < k; ++q) v += U[q * n + 3 + r] * U[q * n + 3 + c];
+                if (r == c) v += d[3 + r];
+            }
+            tp[e] = (TS)v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lowrank_robot(DevState st, int cur, int64_t n_mm, const double *__restrict__ d,
+                                                          const double *__restrict__ U, int64_t k) {
+    const int64_t n = n_mm + 3;
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c < n_mm) {
+        for (int r = 0; r < 3; ++r) {
+            double v = 0.0;
+            for (int64_t q = 0; q < k; ++q) v += U[q * n + r] * U[q * n + 3 + c];
+            st.strip[cur][r * st.ldm + c] = v;
+        }
+    }
+    if (c == 0) {
+        for (int r = 0; r < 3; ++r) for (int b = 0; b < 3; ++b) {
+            double v = 0.0;
+            for (int64_t q = 0; q < k; ++q) v += U[q * n + r] * U[q * n + b];
+            if (r == b) v += d[r];
+            st.prr[cur][3 * r + b] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) { if (tid < s) sh[tid] += sh[tid + s]; __syncthreads(); }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_digest(DevState st, int cur, int64_t n_mm, const int2 *__restrict__ work,
+                                                   int64_t nwork, double *__restrict__ out) {
+    __shared__ double sh[kBlock];
+    const int T = st.tm.T;
+    const TS *__restrict__ tiles = (const TS *)st.tiles;
+    double tr = 0.0, sm = 0.0, sq = 0.0;
+    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+        const int2 ij = work[w];
+        const TS *__restrict__ tp = tiles + st.tm.tile_offset(ij.x, ij.y);
+        for (int e = threadIdx.x; e < T * T; e += kBlock) {
+            const int rr = e >> st.tm.shift, cc = e & (T - 1);
+            const int64_t r = (int64_t)ij.x * T + rr, c = (int64_t)ij.y * T + cc;
+            if (r < n_mm && c <= r) {
+                const double v = (double)tp[e];
+                sm += v; sq += v * v;
+                if (r == c) tr += v;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && st.tm.rank == 0) {
+        // robot block (lower triangle) and strip are replicated: counted once, by shard 0
+        for (int64_t c = threadIdx.x; c < n_mm; c += kBlock)
+            for (int r = 0; r < 3; ++r) { const double v = st.strip[cur][r * st.ldm + c]; sm += v; sq += v * v; }
+        if (threadIdx.x == 0)
+            for (int r = 0; r < 3; ++r) for (int b = 0; b <= r; ++b) {
+                const double v = st.prr[cur][3 * r + b];
+                sm += v; sq += v * v;
+                if (r == b) tr += v;
+            }
+    }
+    tr = block_sum(tr, sh); sm = block_sum(sm, sh); sq = block_sum(sq, sh);
+    if (threadIdx.x == 0) { atomicAdd(out + 0, tr); atomicAdd(out + 1, sm); atomicAdd(out + 2, sq); }
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------------
+#define EKF_STORAGE_DISPATCH(storage, EXPR_F64, EXPR_F32) \
+    do { if ((storage) == 0) { EXPR_F64; } else { EXPR_F32; } } while (0)
+
+hipError_t launch_predict(const DevState &st, const PredictArgs &a, int, hipStream_t s) {
+    const int64_t grid = cdiv(a.n_mm > 0 ? a.n_mm : 1, kBlock);
+    hipLaunchKernelGGL(k_predict, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s) {
+    const int64_t n_mm = 2 * a.N;
+    const int64_t grid = cdiv(n_mm > 0 ? n_mm : 1, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_append<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a),
+        hipLaunchKernelGGL(k_append<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a));
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, hipStream_t s) {
+    const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
+    const int64_t grid = cdiv(cols, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_gather<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a),
+        hipLaunchKernelGGL(k_gather<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a));
+    return hipGetLastError();
+}
+
+template <typename TS>
+static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, hipStream_t s) {
+    if (nwork <= 0) return hipSuccess;
+    int64_t grid = nwork;
+    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+    TS *tiles = (TS *)st.tiles;
+    switch (st.tm.T) {
+        case 16:  hipLaunchKernelGGL((k_downdate<TS, 16>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
+        case 32:  hipLaunchKernelGGL((k_downdate<TS, 32>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
+        case 64:  hipLaunchKernelGGL((k_downdate<TS, 64>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
+        case 128: hipLaunchKernelGGL((k_downdate<TS, 128>), dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int storage, int grid_cap, hipStream_t s) {
+    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, grid_cap, s)
+                        : launch_downdate_t<float>(st, work, nwork, grid_cap, s);
+}
+
+hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
+                            AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s) {
+    const int64_t grid = cdiv(a.N > 0 ? a.N : 1, kAssocBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial),
+        hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_associate_finish, dim3(1), dim3(kAssocBlock), 0, s, partial, grid, a.N, decision);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s) {
+    const int64_t n = n_mm + 3;
+    const int64_t grid = cdiv(n * n, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_unpack_dense<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n, dense),
+        hipLaunchKernelGGL(k_unpack_dense<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n, dense));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s) {
+    const int64_t n = n_mm + 3;
+    const int64_t grid = cdiv(n * n, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_pack_dense<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n, dense),
+        hipLaunchKernelGGL(k_pack_dense<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n, dense));
+    return hipGetLastError();
+}
+
+hipError_t launch_get_block(const DevState &st, int cur, int64_t r0, int64_t c0, int64_t nr, int64_t nc, double *out,
+                            int storage, hipStream_t s) {
+    const int64_t grid = cdiv(nr * nc, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_get_block<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, r0, c0, nr, nc, out),
+        hipLaunchKernelGGL(k_get_block<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, r0, c0, nr, nc, out));
+    return hipGetLastError();
+}
+
+hipError_t launch_lowrank(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, const double *d,
+                          const double *U, int64_t k, int storage, hipStream_t s) {
+    if (nwork > 0) {
+        const int64_t grid = nwork < 65536 ? nwork : 65536;
+        EKF_STORAGE_DISPATCH(storage,
+            hipLaunchKernelGGL(k_lowrank_tiles<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, n_mm, work, nwork, d, U, k),
+            hipLaunchKernelGGL(k_lowrank_tiles<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, n_mm, work, nwork, d, U, k));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int64_t grid = cdiv(n_mm > 0 ? n_mm : 1, kBlock);
+    hipLaunchKernelGGL(k_lowrank_robot, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n_mm, d, U, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_digest(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, double *out,
+                         int storage, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(out, 0, 3 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    int64_t grid = nwork < 2048 ? nwork : 2048;
+    if (grid < 1) grid = 1;
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_digest<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n_mm, work, nwork, out),
+        hipLaunchKernelGGL(k_digest<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n_mm, work, nwork, out));
+    return hipGetLastError();
+}

@@ -1,0 +1,177 @@
+"""Thin object wrapper over the C ABI handle: one Engine == one ekf_handle == one filter state in HBM."""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _vec(v, n=None):
+    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+    if n is not None and a.size != n:
+        raise ValueError("expected %d values, got %d" % (n, a.size))
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _colmajor(M):
+    return np.asfortranarray(np.asarray(M, dtype=np.float64))
+
+
+class Engine:
+    def __init__(self, mode="known", capacity=1024, tile=0, storage="f64", device=0, rank=0, world=1, **overrides):
+        self.lib = L.lib()
+        cfg = L.EkfConfig()
+        m = L.EKF_MODE_KNOWN if mode in ("known", "EKF_SLAM") else L.EKF_MODE_UC
+        self._check(self.lib.ekf_config_default(ctypes.byref(cfg), m), None)
+        cfg.capacity_landmarks = int(capacity)
+        cfg.tile = int(tile)
+        cfg.storage = L.EKF_STORE_F64 if storage == "f64" else L.EKF_STORE_F32
+        cfg.device, cfg.rank, cfg.world = int(device), int(rank), int(world)
+        for k, v in overrides.items():
+            if k == "Rc":
+                cfg.Rc[0], cfg.Rc[1] = float(v[0]), float(v[1])
+            else:
+                setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = ctypes.c_void_p()
+        rc = self.lib.ekf_create(ctypes.byref(cfg), ctypes.byref(self.h))
+        if rc != L.EKF_OK:
+            msg = self.lib.ekf_last_error(self.h).decode() if self.h else ""
+            if self.h:
+                self.lib.ekf_destroy(self.h)
+                self.h = None
+            raise L.EkfError(rc, self.lib.ekf_status_string(rc).decode() + (": " + msg if msg else ""))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ekf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, h="self"):
+        if rc != L.EKF_OK:
+            msg = self.lib.ekf_last_error(self.h).decode() if (h == "self" and self.h) else ""
+            raise L.EkfError(rc, self.lib.ekf_status_string(rc).decode() + (": " + msg if msg else ""))
+
+    # ---- hot path ----
+    def predict(self, u):
+        self._check(self.lib.ekf_predict(self.h, _p(_vec(u, 2))))
+
+    def append(self, u, R, pos, signature):
+        self._check(self.lib.ekf_append(self.h, _p(_vec(u, 2)), _p(_colmajor(R).reshape(-1, order="F")),
+                                        _p(_vec(pos, 2)), float(signature)))
+
+    def correct(self, z, R, idx0):
+        self._check(self.lib.ekf_correct(self.h, _p(_vec(z[:2], 2)), _p(_colmajor(R).reshape(-1, order="F")), int(idx0)))
+
+    def associate(self, z, R, want_costs=False):
+        is_new, idx = ctypes.c_int32(), ctypes.c_int64()
+        N = self.N
+        pc = np.zeros(max(N, 1)) if want_costs else None
+        sc = np.zeros(max(N, 1)) if want_costs else None
+        self._check(self.lib.ekf_associate(self.h, _p(_vec(z, 3)), _p(_colmajor(R).reshape(-1, order="F")),
+                                           ctypes.byref(is_new), ctypes.byref(idx),
+                                           _p(pc) if want_costs else None, _p(sc) if want_costs else None))
+        if want_costs:
+            return bool(is_new.value), int(idx.value), pc[:N], sc[:N]
+        return bool(is_new.value), int(idx.value)
+
+    def measure(self, observed_LL, u, lm_index, lm_loc):
+        obs = np.asfortranarray(np.asarray(observed_LL, dtype=np.float64).reshape(-1, 3))
+        idx = _vec(lm_index)
+        loc = np.asfortranarray(np.asarray(lm_loc, dtype=np.float64).reshape(-1, 2))
+        self._check(self.lib.ekf_measure(self.h, _p(obs.reshape(-1, order="F")), obs.shape[0], _p(_vec(u, 2)),
+                                         _p(idx), _p(loc.reshape(-1, order="F")), idx.size))
+
+    def sync(self):
+        self._check(self.lib.ekf_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.ekf_set_stream(self.h, ctypes.c_void_p(stream_ptr)))
+
+    # ---- state ----
+    @property
+    def N(self):
+        n = ctypes.c_int64()
+        self._check(self.lib.ekf_num_landmarks(self.h, ctypes.byref(n)))
+        return int(n.value)
+
+    @property
+    def n(self):
+        return 3 + 2 * self.N
+
+    def get_x(self):
+        x = np.empty(self.n)
+        self._check(self.lib.ekf_get_x(self.h, _p(x)))
+        return x
+
+    def get_s(self):
+        s = np.empty(max(self.N, 1))
+        self._check(self.lib.ekf_get_s(self.h, _p(s)))
+        return s[:self.N]
+
+    def get_P(self):
+        n = self.n
+        buf = np.empty(n * n)
+        self._check(self.lib.ekf_get_P(self.h, _p(buf)))
+        return buf.reshape(n, n, order="F")
+
+    def get_P_block(self, r0, c0, nr, nc):
+        buf = np.empty(nr * nc)
+        self._check(self.lib.ekf_get_P_block(self.h, r0, c0, nr, nc, _p(buf)))
+        return buf.reshape(nr, nc, order="F")
+
+    def get_Q3(self):
+        q = np.empty(9)
+        self._check(self.lib.ekf_get_Q(self.h, _p(q)))
+        return q.reshape(3, 3, order="F")
+
+    def set_state(self, x, P, s):
+        x = _vec(x)
+        self._check(self.lib.ekf_set_x(self.h, _p(x), x.size))
+        s = _vec(s)
+        self._check(self.lib.ekf_set_s(self.h, _p(s) if s.size else None, s.size))
+        Pf = np.asfortranarray(np.asarray(P, dtype=np.float64))
+        self._check(self.lib.ekf_set_P(self.h, _p(Pf.reshape(-1, order="F")), Pf.shape[0]))
+
+    def load_lowrank_state(self, x, s, d, U):
+        x, s, d = _vec(x), _vec(s), _vec(d)
+        U = np.asfortranarray(np.asarray(U, dtype=np.float64))
+        N = (x.size - 3) // 2
+        self._check(self.lib.ekf_load_lowrank_state(self.h, N, _p(x), _p(s) if s.size else _p(np.zeros(1)), _p(d),
+                                                    _p(U.reshape(-1, order="F")), U.shape[1]))
+
+    def digest(self):
+        out = np.empty(3)
+        self._check(self.lib.ekf_P_digest(self.h, _p(out)))
+        return out
+
+    def device_bytes(self):
+        b = ctypes.c_int64()
+        self._check(self.lib.ekf_device_bytes(self.h, ctypes.byref(b)))
+        return int(b.value)
+
+    # ---- measurement hooks ----
+    def timing_enable(self, which, on=True):
+        self._check(self.lib.ekf_kernel_timing_enable(self.h, which, 1 if on else 0))
+
+    def timing_read(self, which):
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        self._check(self.lib.ekf_kernel_timing_read(self.h, which, ctypes.byref(n), ctypes.byref(ms)))
+        return int(n.value), float(ms.value)
+
+    def downdate_algorithmic_bytes(self):
+        b = ctypes.c_int64()
+        self._check(self.lib.ekf_downdate_algorithmic_bytes(self.h, ctypes.byref(b)))
+        return int(b.value)

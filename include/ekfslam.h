@@ -1,0 +1,154 @@
+/*
+ * libekfslam -- C ABI of the MI355X-native EKF-SLAM update engine.
+ *
+ * The reference (SamShue/EKF_SLAM) is pure MATLAB and has NO plugin / operator / FFI interface; its
+ * boundary is the class-method surface of EKF_SLAM.m / EKF_SLAM_UC.m / Correspondence.m / append.m.  Each
+ * entry point below names the reference method it replaces (file:line in the reference tree).  A MEX
+ * gateway (matlab/ekfslam_mex.c) and a ctypes binding (ekf_slam_amd/_lib.py) bind exactly these symbols.
+ *
+ * Conventions
+ *   - every call returns an int32 status (EKF_OK == 0) and never throws across the ABI;
+ *     ekf_last_error(h) gives the message of the last failure on that handle;
+ *   - arrays are caller-owned HOST buffers of IEEE doubles; matrices are COLUMN-MAJOR (MATLAB native);
+ *   - landmark indices are 0-BASED here (the MEX / Python layers convert from the reference's 1-based);
+ *   - angles are degrees, exactly as in the reference;
+ *   - a handle is not thread-safe; all work is queued on the handle's HIP stream and calls that return
+ *     data synchronise that stream, the others are asynchronous;
+ *   - state lives in HBM: x (3+2N), s (N) and P in a tiled symmetric block layout (3x3 robot block,
+ *     3 x 2N robot/landmark strip, T x T tiles of the lower block triangle of the landmark block).
+ */
+#ifndef EKFSLAM_H
+#define EKFSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EKF_ABI_VERSION 1
+
+enum {
+    EKF_OK = 0,
+    EKF_ERR_INVALID_ARG = 1,
+    EKF_ERR_NO_DEVICE = 2,   /* no HIP device / HIP runtime failure at create */
+    EKF_ERR_HIP = 3,         /* a HIP call failed; see ekf_last_error         */
+    EKF_ERR_CAPACITY = 4,    /* append beyond capacity_landmarks              */
+    EKF_ERR_INDEX = 5,       /* landmark index outside the state              */
+    EKF_ERR_LOOKUP = 6,      /* landmark-table lookup did not match exactly one entry (MATLAB would error) */
+    EKF_ERR_STATE = 7,       /* call not valid in the handle's current state  */
+    EKF_ERR_COMM = 8         /* multi-GPU exchange failed                     */
+};
+
+enum { EKF_MODE_KNOWN = 0,   /* EKF_SLAM.m    : known correspondence   */
+       EKF_MODE_UC = 1 };    /* EKF_SLAM_UC.m : unknown correspondence */
+
+enum { EKF_STORE_F64 = 0,    /* P tiles stored as double                               */
+       EKF_STORE_F32 = 1 };  /* P tiles stored as float, every solve still in double   */
+
+/* Hard-coded property defaults of the reference collected in one struct
+ * (EKF_SLAM.m:12-16, EKF_SLAM_UC.m:13,16). */
+typedef struct ekf_config {
+    double  C;                   /* process-noise constant              EKF_SLAM.m:12               */
+    double  Rc[2];               /* measurement-noise constants         EKF_SLAM.m:13 / _UC.m:13    */
+    double  s_cost;              /* signature cost                      EKF_SLAM.m:14 / _UC.m:16    */
+    double  s_thresh;            /* new-landmark threshold              EKF_SLAM.m:16 / _UC.m:16    */
+    double  w_pos;               /* weight of the Mahalanobis position cost in the association
+                                    likelihood; 0 reproduces the live line Correspondence.m:75,
+                                    1 the commented-out line Correspondence.m:74                    */
+    int64_t capacity_landmarks;  /* HBM is sized for this many landmarks (streaming append never reallocates) */
+    int32_t mode;                /* EKF_MODE_*  (selects the ekf_measure dispatch)                  */
+    int32_t storage;             /* EKF_STORE_*                                                     */
+    int32_t device;              /* HIP device ordinal                                              */
+    int32_t tile;                /* tile edge T in elements: 16, 32, 64 or 128; 0 = default (64)    */
+    int32_t rank;                /* shard rank  (0 when world == 1)                                 */
+    int32_t world;               /* number of shards P is split over; 0 or 1 = unsharded            */
+    int32_t reserved[8];
+} ekf_config;
+
+typedef struct ekf_handle ekf_handle;
+
+/* ---- library ---- */
+int32_t     ekf_abi_version(void);
+const char *ekf_status_string(int32_t status);
+/* Fill *cfg with the reference's property defaults for `mode` (Rc = [.01,5] known, [.1,5] UC). */
+int32_t     ekf_config_default(ekf_config *cfg, int32_t mode);
+
+/* ---- lifecycle: EKF_SLAM() / EKF_SLAM_UC() constructors (EKF_SLAM.m:26-34, EKF_SLAM_UC.m:27-36):
+ *      x = [0 0 0], P = 0.1*eye(3), s = [] ---- */
+int32_t     ekf_create(const ekf_config *cfg, ekf_handle **out);
+int32_t     ekf_destroy(ekf_handle *h);
+const char *ekf_last_error(const ekf_handle *h);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL restores the
+ * handle's own stream. */
+int32_t     ekf_set_stream(ekf_handle *h, void *hip_stream);
+int32_t     ekf_sync(ekf_handle *h);
+
+/* ---- hot path ---- */
+/* predict(h,u)  EKF_SLAM.m:40-51 (EKF_SLAM_UC.m:42-53): u = [dD, dTheta_deg]. */
+int32_t ekf_predict(ekf_handle *h, const double u[2]);
+
+/* [x_new,F] = f(h,x,u)  EKF_SLAM.m:56-65: pure host function on caller arrays (public method of the
+ * reference).  x, x_new: n doubles; F: n x n column-major or NULL. */
+int32_t ekf_motion_model(const double *x, int64_t n, const double u[2], double *x_new, double *F);
+
+/* append(h,u,R,landmarkPos,signature)  EKF_SLAM.m:67-98 (EKF_SLAM_UC.m:69-100).  R: 2x2 column-major. */
+int32_t ekf_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature);
+
+/* Correction body of measure()  EKF_SLAM.m:124-145 (EKF_SLAM_UC.m:125-146) for landmark `idx` (0-based):
+ * innovation, H_k, phi_k, K, x += K nu, P = (I - K H_k) P.  z = [range, bearing_deg]. */
+int32_t ekf_correct(ekf_handle *h, const double z[2], const double R[4], int64_t idx);
+
+/* [newLL,index] = estimateCorrespondence(h,z,R,x,P,s)  Correspondence.m:28-88 on the handle's x, P, s.
+ * z = [range, bearing_deg, signature].  *idx is 0-based (== N for a new landmark).  pos_cost / sig_cost:
+ * optional N-element outputs (Correspondence.m:69,71), may be NULL. */
+int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
+                      double *pos_cost, double *sig_cost);
+
+/* measure(h,laserData,u,landmark_list) AFTER the landmark front-end has run, i.e. the loop
+ * EKF_SLAM.m:105-150 / EKF_SLAM_UC.m:107-151 over observed_LL (m x 3 column-major [range, bearing_deg, index]).
+ * The landmark struct array the loop looks `loc` up in (landmark_list.landmarkObj.landmark(k).index/.loc,
+ * EKF_SLAM.m:111,120) is passed as lm_index (L) and lm_loc (L x 2 column-major).  Dispatch follows
+ * cfg.mode, including the reference's quirks: the empty-map row only appends (signature 1), the
+ * known-correspondence branch corrects landmark ii (the row number, EKF_SLAM.m:123), R = diag(z1*Rc1, z2*Rc2). */
+int32_t ekf_measure(ekf_handle *h, const double *observed_LL, int64_t m, const double u[2],
+                    const double *lm_index, const double *lm_loc, int64_t L);
+
+/* ---- state access (the reference's public properties x, P, Q, s; EKF_SLAM.m:6-9) ---- */
+int32_t ekf_num_landmarks(ekf_handle *h, int64_t *N);
+int32_t ekf_get_x(ekf_handle *h, double *x /* 3+2N */);
+int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n);
+int32_t ekf_get_s(ekf_handle *h, double *s /* N */);
+int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N);
+/* Dense n x n column-major P.  set_P stores the lower triangle (P is a covariance: symmetric). */
+int32_t ekf_get_P(ekf_handle *h, double *P);
+int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n);
+/* P(r0:r0+nr-1, c0:c0+nc-1) into out (nr x nc column-major): what plot() reads (EKF_SLAM.m:180,205). */
+int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64_t nc, double *out);
+/* The 3x3 non-zero block of the last predict's Q (EKF_SLAM.m:43-44), column-major. */
+int32_t ekf_get_Q(ekf_handle *h, double Q[9]);
+/* Bulk state load used to start large benchmarks: sets N landmarks, x (3+2N), s (N) and
+ * P = diag(d) + U U' with d (3+2N) > 0 and U ((3+2N) x k column-major), built tile by tile on the device. */
+int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const double *s,
+                               const double *d, const double *U, int64_t k);
+/* Order-independent digests of P computed on the device over the unique (lower-triangle) entries:
+ * out[0] = trace, out[1] = sum of the lower triangle incl. diagonal, out[2] = sum of squares of it. */
+int32_t ekf_P_digest(ekf_handle *h, double out[3]);
+/* Bytes of HBM held by the handle (all buffers). */
+int32_t ekf_device_bytes(ekf_handle *h, int64_t *bytes);
+
+/* ---- measurement hooks ---- */
+enum { EKF_KERNEL_DOWNDATE = 0, EKF_KERNEL_GATHER = 1, EKF_KERNEL_PREDICT = 2, EKF_KERNEL_ASSOCIATE = 3,
+       EKF_KERNEL_APPEND = 4, EKF_KERNEL_COUNT = 5 };
+/* Bracket every launch of kernel `which` with HIP events on the handle's stream (on != 0) and read the
+ * accumulated launch count and device time; reading synchronises the stream and resets the counters. */
+int32_t ekf_kernel_timing_enable(ekf_handle *h, int32_t which, int32_t on);
+int32_t ekf_kernel_timing_read(ekf_handle *h, int32_t which, int64_t *launches, double *total_ms);
+/* Algorithmic bytes one launch of the downdate kernel moves at the current N: every unique entry of the
+ * symmetric P read once and written once = w * n * (n+1), n = 3+2N. */
+int32_t ekf_downdate_algorithmic_bytes(ekf_handle *h, int64_t *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EKFSLAM_H */

@@ -110,9 +110,15 @@ double *oekf_P(oekf *h) { return h->P; }
 double *oekf_s(oekf *h) { return h->s; }
 double *oekf_Q(oekf *h) { return h->Q; }
 void oekf_set_num_landmarks(oekf *h, int64_t N) { h->N = N; }
+/* OpenMP is used only above OEKF_PAR_MIN rows (small states stay single-threaded: a parallel region costs
+ * more than the whole update there, and far more when the host exposes more hardware threads than the
+ * process may use). */
+#define OEKF_PAR_MIN 1024
+static int g_threads = 1;
+void oekf_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
 int oekf_threads(void) {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    return g_threads;
 #else
     return 1;
 #endif
@@ -204,7 +210,7 @@ int oekf_correct(oekf *h, const double z[2], const double R[4], int64_t idx) {
     innovation_terms(x, idx - 1, zhat, Hs);
     const int64_t S[5] = { 0, 1, 2, j, j + 1 };
     /* HP = H_s P(S,:) (rows), PHt = P(:,S) H_s' (columns) */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (n >= OEKF_PAR_MIN)
     for (int64_t c = 0; c < n; ++c) {
         for (int a = 0; a < 2; ++a) {
             double r = 0, cc = 0;
@@ -219,7 +225,7 @@ int oekf_correct(oekf *h, const double z[2], const double R[4], int64_t idx) {
     inv2(phi, iphi);
     const double nu0 = z[0] - zhat[0], nu1 = z[1] - zhat[1];
     /* K = PHt * inv(phi) ; x += K nu ; P -= K * HP */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (n >= OEKF_PAR_MIN)
     for (int64_t i = 0; i < n; ++i) {
         const double k0 = pht[i] * iphi[0] + pht[ld + i] * iphi[2];
         const double k1 = pht[i] * iphi[1] + pht[ld + i] * iphi[3];

@@ -20,6 +20,19 @@ _dp = ctypes.POINTER(ctypes.c_double)
 _i64 = ctypes.c_int64
 
 
+def available_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "libekf_oracle.so"])
 
@@ -54,6 +67,8 @@ def lib():
             getattr(L, name).restype = _d
             getattr(L, name).argtypes = [_d]
         L.oekf_threads.restype = ctypes.c_int
+        L.oekf_set_threads.argtypes = [ctypes.c_int]
+        L.oekf_set_threads(available_cores())
         _LIB = L
     return _LIB
 
