@@ -1,0 +1,136 @@
+"""CPU tests of the oracle (test infrastructure): hand-derived known-answer tests from the reference source
+(SURVEY.md section 4, KAT-1..4 -- the reference itself holds no golden vectors: PARITY UNPINNED), and
+literal-dense == structured agreement."""
+import numpy as np
+import pytest
+
+from ekf_slam_amd.world import SyntheticLandmark, make_run
+from oracle import ekf_dense as D
+from oracle.ekf_structured import StructuredEKF
+from oracle.matlab_compat import atan2d, cosd, inv2, sind, wrapTo360
+
+
+def rel_err(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+
+def test_kat1_predict_from_ctor_state_dense():
+    # EKF_SLAM.m:28-31,42-50,58-64 by hand: W=[1;0;0], Q_rr=diag(.2,0,0), F(1,3)=0, F(2,3)=1
+    e = D.EKF_SLAM()
+    e.predict([1, 0])
+    np.testing.assert_allclose(e.x, [1, 0, 0], atol=0)
+    np.testing.assert_allclose(e.P, [[0.3, 0, 0], [0, 0.2, 0.1], [0, 0.1, 0.1]], atol=1e-16)
+
+
+def test_kat1_structured(oracle_lib):
+    e = StructuredEKF(4, "known")
+    e.predict([1, 0])
+    np.testing.assert_allclose(e.x, [1, 0, 0], atol=0)
+    np.testing.assert_allclose(e.P, [[0.3, 0, 0], [0, 0.2, 0.1], [0, 0.1, 0.1]], atol=1e-16)
+    np.testing.assert_allclose(e.Q, np.diag([0.2, 0, 0]), atol=1e-16)
+
+
+def test_kat2_degree_builtins(oracle_lib):
+    assert wrapTo360(360.0) == 360.0 and wrapTo360(720.0) == 360.0 and wrapTo360(0.0) == 0.0
+    assert wrapTo360(-90.0) == 270.0 and wrapTo360(450.0) == 90.0 and wrapTo360(-360.0) == 0.0
+    for a, s, c in [(0, 0, 1), (90, 1, 0), (180, 0, -1), (270, -1, 0), (360, 0, 1), (-90, -1, 0), (450, 1, 0)]:
+        assert sind(a) == s and cosd(a) == c
+        assert oracle_lib.oekf_sind(a) == s and oracle_lib.oekf_cosd(a) == c
+    for a in np.linspace(-720, 720, 97):
+        assert abs(sind(a) - np.sin(np.deg2rad(a))) < 1e-14
+        assert abs(cosd(a) - np.cos(np.deg2rad(a))) < 1e-14
+        assert sind(a) == oracle_lib.oekf_sind(a) and cosd(a) == oracle_lib.oekf_cosd(a)
+        assert wrapTo360(a) == oracle_lib.oekf_wrapTo360(a)
+    assert atan2d(1, 0) == 90.0 and atan2d(0, -1) == 180.0
+    A = np.array([[2.0, 1.0], [0.5, 3.0]])
+    np.testing.assert_allclose(inv2(A), np.linalg.inv(A), rtol=1e-15)
+    B = np.array([[0.1, 2.0], [4.0, 1.0]])      # pivoting branch
+    np.testing.assert_allclose(inv2(B), np.linalg.inv(B), rtol=1e-15)
+
+
+def test_kat3_first_observation_only_appends():
+    # EKF_SLAM.m:110-111: with length(x) < 4 the row appends (signature 1) and performs no correction
+    e = D.EKF_SLAM()
+    lm = SyntheticLandmark()
+    e.predict([0.1, 3.0])
+    x_before, P_before = e.x.copy(), e.P.copy()
+    e.measure([(0, 2.0, 30.0)], [0.1, 3.0], lm)
+    assert len(e.x) == 5 and e.s == [1]
+    np.testing.assert_array_equal(e.x[:3], x_before)
+    np.testing.assert_array_equal(e.P[:3, :3], P_before)
+
+
+def test_kat3_malformed_first_row_raises():
+    e = D.EKF_SLAM()
+    lm = SyntheticLandmark()
+    with pytest.raises(D.LandmarkLookupError):
+        e.measure([(0, 2.0, 30.0), (1, 3.0, 40.0)], [0.1, 3.0], lm)   # two indexed landmarks: find([index]) has 2 hits
+
+
+def test_kat4_association_is_signature_only():
+    # Correspondence.m:71-85: (false,k) iff some s(k) == z(3) (first such k), else (true, N+1)
+    rng = np.random.default_rng(0)
+    N = 6
+    x = np.concatenate([[0, 0, 10.0], rng.uniform(-5, 5, 2 * N)])
+    A = rng.normal(size=(3 + 2 * N, 3 + 2 * N))
+    P = A @ A.T + np.eye(3 + 2 * N)
+    s = [1, 2, 3, 4, 3, 6]
+    c = D.Correspondence(1e-11, 1e9, 'EKF_SLAM_UC')
+    R = np.diag([0.1, 5.0])
+    assert c.estimateCorrespondence([3.0, 20.0, 3], R, x, P, s) == (False, 3)
+    assert c.estimateCorrespondence([3.0, 20.0, 6], R, x, P, s) == (False, 6)
+    assert c.estimateCorrespondence([3.0, 20.0, 7], R, x, P, s) == (True, N + 1)
+    assert c.estimateCorrespondence([3.0, 20.0, 3.05], R, x, P, s) == (False, 3)      # |d| <= 0.1 passes the threshold
+    assert c.estimateCorrespondence([3.0, 20.0, 3.2], R, x, P, s) == (True, N + 1)
+    with pytest.warns(UserWarning):
+        assert D.Correspondence(1e-11, 1e9, 'other').method == 'ML'                    # Correspondence.m:19-23
+
+
+def test_append_free_function_guard():
+    # append.m:4: only appends when numOfLandmarks < idx
+    x = np.array([0.0, 0, 0, 1, 1])
+    P = np.eye(5)
+    x2, P2 = D.append(x, P, [0.1, 1], 1, np.eye(2), [2, 2])
+    assert len(x2) == 5 and P2.shape == (5, 5)
+    x3, P3 = D.append(x, P, [0.1, 1], 2, np.eye(2), [2, 2])
+    assert len(x3) == 7 and P3.shape == (7, 7)
+    np.testing.assert_allclose(P3, P3.T, atol=1e-15)
+
+
+@pytest.mark.parametrize("mode", ["known", "uc"])
+def test_dense_equals_structured_20_landmarks(mode, oracle_lib):
+    _, run = make_run(20, 20260101, 60, policy="all")
+    d = (D.EKF_SLAM if mode == "known" else D.EKF_SLAM_UC)()
+    st = StructuredEKF(32, mode)
+    la, lb = SyntheticLandmark(), SyntheticLandmark()
+    for u, scan in run:
+        d.predict(u); st.predict(u)
+        d.measure(scan, u, la); st.measure(scan, u, lb)
+        assert rel_err(st.x, d.x) < 1e-11 and rel_err(st.P, d.P) < 1e-11
+    assert st.N == 20 and list(st.s) == list(d.s)
+    # invariants: symmetric to rounding, PSD
+    assert np.abs(d.P - d.P.T).max() < 1e-12
+    assert np.linalg.eigvalsh((d.P + d.P.T) / 2).min() > -1e-10
+
+
+def test_dense_equals_structured_200_landmarks_uc(oracle_lib):
+    _, run = make_run(200, 20260102, 6, policy="nearest", m=8)
+    d, st = D.EKF_SLAM_UC(), StructuredEKF(256, "uc")
+    la, lb = SyntheticLandmark(), SyntheticLandmark()
+    for u, scan in run:
+        d.predict(u); st.predict(u)
+        d.measure(scan, u, la); st.measure(scan, u, lb)
+    assert st.N == 200
+    assert rel_err(st.x, d.x) < 1e-11 and rel_err(st.P, d.P) < 1e-11
+
+
+def test_trace_non_increasing_across_correction(oracle_lib):
+    _, run = make_run(20, 20260101, 10, policy="all")
+    st = StructuredEKF(32, "known")
+    lb = SyntheticLandmark()
+    for u, scan in run:
+        st.predict(u); st.measure(scan, u, lb)
+    z = [3.0, 45.0]
+    before = np.trace(st.P)
+    st.correct(z, np.diag([0.03, 225.0]), 4)
+    assert np.trace(st.P) <= before + 1e-12
