@@ -14,6 +14,7 @@ EKF_OK = 0
 EKF_ERR_INVALID_ARG, EKF_ERR_NO_DEVICE, EKF_ERR_HIP, EKF_ERR_CAPACITY = 1, 2, 3, 4
 EKF_ERR_INDEX, EKF_ERR_LOOKUP, EKF_ERR_STATE, EKF_ERR_COMM = 5, 6, 7, 8
 EKF_MODE_KNOWN, EKF_MODE_UC = 0, 1
+EKF_COMM_ID_BYTES = 128
 EKF_STORE_F64, EKF_STORE_F32 = 0, 1
 (EKF_KERNEL_DOWNDATE, EKF_KERNEL_GATHER, EKF_KERNEL_PREDICT, EKF_KERNEL_ASSOCIATE, EKF_KERNEL_APPEND,
  EKF_KERNEL_COUNT) = range(6)
@@ -48,6 +49,17 @@ SIGNATURES = {
     "ekf_correct": (_i32, [_vp, _dp, _dp, _i64]),
     "ekf_associate": (_i32, [_vp, _dp, _dp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), _dp, _dp]),
     "ekf_measure": (_i32, [_vp, _dp, _i64, _dp, _dp, _dp, _i64]),
+    "ekf_comm_unique_id": (_i32, [ctypes.c_char_p]),
+    "ekf_comm_init": (_i32, [_vp, ctypes.c_char_p]),
+    "ekf_correct_begin": (_i32, [_vp, _dp, _dp, _i64]),
+    "ekf_correct_finish": (_i32, [_vp]),
+    "ekf_exchange_info": (_i32, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64),
+                                 ctypes.POINTER(_i64)]),
+    "ekf_exchange_set_buffers": (_i32, [_vp, _vp, _vp]),
+    "ekf_exchange_local": (_i32, [ctypes.POINTER(_vp), _i32]),
+    "ekf_shard_owner": (_i32, [_i32, _i64, _i64]),
+    "ekf_shard_slot": (_i64, [_i32, _i64, _i64]),
+    "ekf_shard_panel_source": (_i32, [_i32, _i64, _i64, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
     "ekf_num_landmarks": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "ekf_get_x": (_i32, [_vp, _dp]),
     "ekf_set_x": (_i32, [_vp, _dp, _i64]),
@@ -85,6 +97,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libekfslam.so is not built (%s); run __graft_entry__.build() or "
                               "`make -C ekf_slam_amd/csrc` -- there is no fallback path" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 / librccl (sonames
+        # libamdhip64.so.7 / librccl.so.1).  If torch is going to be used in this process (streams,
+        # torch.distributed) it must be loaded FIRST so that libekfslam's NEEDED libamdhip64.so.7 and its
+        # dlopen("librccl.so.1") bind to the copies torch already mapped; loading /opt/rocm's copy first and
+        # torch's second leaves two runtimes fighting over the device ("No HIP GPUs are available").
+        if os.environ.get("EKF_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)       # AttributeError if the library lacks a declared symbol

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +24,39 @@ struct KernelTimer {
     size_t used = 0;              // events used since the last read
 };
 
+// RCCL is bound at run time (dlopen) so that single-GPU users never load it.
+struct RcclApi {
+    void *dl = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, ekf_comm_id, int) = nullptr;      // ncclUniqueId is 128 opaque bytes by value
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+static RcclApi g_rccl;
+
+static bool rccl_load(std::string &err) {
+    if (g_rccl.dl) return true;
+    const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void *dl = nullptr;
+    for (const char *n : names) { dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (dl) break; }
+    if (!dl) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
+    RcclApi a;
+    a.dl = dl;
+    a.GetUniqueId = (int (*)(void *))dlsym(dl, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void **, int, ekf_comm_id, int))dlsym(dl, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(dl, "ncclAllGather");
+    a.CommDestroy = (int (*)(void *))dlsym(dl, "ncclCommDestroy");
+    a.GetErrorString = (const char *(*)(int))dlsym(dl, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy || !a.GetErrorString) {
+        err = "librccl lacks a required symbol";
+        return false;
+    }
+    g_rccl = a;
+    return true;
+}
+
 struct ekf_handle {
     ekf_config cfg;
     int64_t N = 0;         // landmarks in the state (host mirror; appends are host-initiated)
@@ -37,6 +72,14 @@ struct ekf_handle {
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
+    // sharded correction: exchange slabs (own allocations, or caller-provided device buffers)
+    bool sharded = false;          // world > 1, or forced (EKF_FORCE_SHARDED=1) to exercise the path on one GPU
+    double *own_send = nullptr, *own_recv = nullptr, *send = nullptr, *recv = nullptr;
+    int64_t slab_cap = 0;          // doubles per shard slab at capacity
+    int64_t slab = 0;              // doubles per shard slab of the pending correction
+    bool pending = false;
+    CorrectArgs pending_args;
+    void *comm = nullptr;          // ncclComm_t
     KernelTimer timers[EKF_KERNEL_COUNT];
     std::vector<void *> allocs;
     int64_t bytes = 0;
@@ -151,7 +194,59 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     return EKF_OK;
 }
 
+int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
+    const int64_t nt = ekf_tiles_for(mm_rows, h->T);
+    const int64_t cmax = (nt + h->cfg.world - 1) / h->cfg.world;
+    return cmax * h->T * 2;
+}
+
+int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
+    REQUIRE(h, !h->pending, EKF_ERR_STATE, "correct_begin: a correction is already pending");
+    int32_t rc = refresh_work(h);
+    if (rc) return rc;
+    CorrectArgs &a = h->pending_args;
+    a.z0 = z[0]; a.z1 = z[1];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur;
+    h->slab = slab_for(h, a.n_mm);
+    HIPCHK(h, launch_rowpanel(h->st, a.j, a.n_mm, h->send, h->storage, h->stream));
+    h->pending = true;
+    return EKF_OK;
+}
+
+int32_t correct_finish(ekf_handle *h) {
+    REQUIRE(h, h->pending, EKF_ERR_STATE, "correct_finish: no correction pending");
+    h->pending = false;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_GATHER);
+        HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, h->recv, h->slab, h->storage, h->stream));
+    }
+    h->cur ^= 1;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
+        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->storage, h->grid_cap, h->stream));
+    }
+    return EKF_OK;
+}
+
+int32_t exchange_rccl(ekf_handle *h) {
+    REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
+            "sharded handle without a communicator: call ekf_comm_init, or drive ekf_correct_begin / your own "
+            "all-gather / ekf_correct_finish");
+    const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->slab, /*ncclDouble*/ 8, h->comm, h->stream);
+    if (r != 0) { h->pending = false; return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r)); }
+    return EKF_OK;
+}
+
 int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    if (h->sharded) {
+        int32_t rc = correct_begin(h, z, R, idx);
+        if (rc) return rc;
+        rc = exchange_rccl(h);
+        if (rc) { h->pending = false; return rc; }
+        return correct_finish(h);
+    }
     REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
     int32_t rc = refresh_work(h);
     if (rc) return rc;
@@ -174,6 +269,8 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
 int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
                      double *pos_cost, double *sig_cost) {
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
+    REQUIRE(h, h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
+            "associate: w_pos != 0 needs the diagonal blocks of other shards (not supported on a sharded handle)");
     AssocArgs a;
     a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
@@ -306,6 +403,17 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->d_pos_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_sig_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_digest, 4));
+    {
+        const char *fs = getenv("EKF_FORCE_SHARDED");
+        h->sharded = world > 1 || (fs && atoi(fs) != 0);
+        if (h->sharded) {
+            h->slab_cap = slab_for(h, 2 * h->cap);
+            HIPCHK(h, dalloc(h, &h->own_send, (size_t)h->slab_cap));
+            HIPCHK(h, dalloc(h, &h->own_recv, (size_t)(h->slab_cap * world)));
+            h->send = h->own_send;
+            h->recv = h->own_recv;
+        }
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_decision, sizeof(AssocDecision), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
 
@@ -324,6 +432,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (!h) return EKF_OK;
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);
@@ -433,6 +542,100 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
     return EKF_OK;
 }
 
+int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    if (!h || !z || !R) return fail(h, EKF_ERR_INVALID_ARG, "correct_begin: null argument");
+    REQUIRE(h, h->sharded, EKF_ERR_STATE, "correct_begin: handle is not sharded (use ekf_correct)");
+    int32_t rc = use_device(h);
+    return rc ? rc : correct_begin(h, z, R, idx);
+}
+
+int32_t ekf_correct_finish(ekf_handle *h) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    int32_t rc = use_device(h);
+    return rc ? rc : correct_finish(h);
+}
+
+int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    REQUIRE(h, h->sharded, EKF_ERR_STATE, "exchange_info: handle is not sharded");
+    if (send) *send = h->send;
+    if (recv) *recv = h->recv;
+    if (count) *count = h->slab;
+    if (count_capacity) *count_capacity = h->slab_cap;
+    return EKF_OK;
+}
+
+int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    REQUIRE(h, h->sharded && !h->pending, EKF_ERR_STATE, "exchange_set_buffers: not sharded, or a correction is pending");
+    h->send = send ? (double *)send : h->own_send;
+    h->recv = recv ? (double *)recv : h->own_recv;
+    return EKF_OK;
+}
+
+int32_t ekf_exchange_local(ekf_handle **hs, int32_t world) {
+    if (!hs || world < 1) return EKF_ERR_INVALID_ARG;
+    for (int r = 0; r < world; ++r) {
+        if (!hs[r]) return EKF_ERR_INVALID_ARG;
+        REQUIRE(hs[r], hs[r]->sharded && hs[r]->cfg.world == world && hs[r]->cfg.rank == r && hs[r]->pending &&
+                           hs[r]->slab == hs[0]->slab,
+                EKF_ERR_STATE, "exchange_local: handles must be the shards 0..world-1 of one filter, each with a pending correction");
+    }
+    // producers first: every shard's send slab must be complete before anyone copies it
+    for (int r = 0; r < world; ++r) {
+        HIPCHK(hs[r], hipSetDevice(hs[r]->cfg.device));
+        HIPCHK(hs[r], hipStreamSynchronize(hs[r]->stream));
+    }
+    const size_t bytes = (size_t)hs[0]->slab * sizeof(double);
+    for (int dst = 0; dst < world; ++dst) {
+        ekf_handle *d = hs[dst];
+        HIPCHK(d, hipSetDevice(d->cfg.device));
+        for (int src = 0; src < world; ++src)
+            HIPCHK(d, hipMemcpyPeerAsync(d->recv + (size_t)src * d->slab, d->cfg.device, hs[src]->send,
+                                         hs[src]->cfg.device, bytes, d->stream));
+    }
+    return EKF_OK;
+}
+
+int32_t ekf_comm_unique_id(ekf_comm_id *id) {
+    if (!id) return EKF_ERR_INVALID_ARG;
+    std::string err;
+    if (!rccl_load(err)) return EKF_ERR_COMM;
+    return g_rccl.GetUniqueId(id) == 0 ? EKF_OK : EKF_ERR_COMM;
+}
+
+int32_t ekf_comm_init(ekf_handle *h, const ekf_comm_id *id) {
+    if (!h || !id) return fail(h, EKF_ERR_INVALID_ARG, "comm_init: null argument");
+    REQUIRE(h, h->sharded, EKF_ERR_STATE, "comm_init: handle is not sharded");
+    REQUIRE(h, h->comm == nullptr, EKF_ERR_STATE, "comm_init: communicator already attached");
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    std::string err;
+    if (!rccl_load(err)) return fail(h, EKF_ERR_COMM, err.c_str());
+    void *comm = nullptr;
+    const int r = g_rccl.CommInitRank(&comm, h->cfg.world, *id, h->cfg.rank);
+    if (r != 0) return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r));
+    h->comm = comm;
+    return EKF_OK;
+}
+
+int32_t ekf_shard_owner(int32_t world, int64_t I, int64_t J) {
+    if (world < 1 || I < 0 || J < 0) return -1;
+    return ekf_make_tilemap(64, world, 0).owner(I, J);
+}
+
+int64_t ekf_shard_slot(int32_t world, int64_t I, int64_t J) {
+    if (world < 1 || I < 0 || J < 0 || J > I) return -1;
+    return ekf_make_tilemap(64, world, 0).slot(I, J);
+}
+
+int32_t ekf_shard_panel_source(int32_t world, int64_t tile_row_j, int64_t chunk, int32_t *owner, int64_t *local_chunk) {
+    if (world < 1 || tile_row_j < 0 || chunk < 0 || !owner || !local_chunk) return EKF_ERR_INVALID_ARG;
+    *owner = (int32_t)((tile_row_j + chunk) % world);
+    *local_chunk = chunk / world;
+    return EKF_OK;
+}
+
 int32_t ekf_num_landmarks(ekf_handle *h, int64_t *N) {
     if (!h || !N) return fail(h, EKF_ERR_INVALID_ARG, "num_landmarks: null argument");
     *N = h->N;
@@ -480,7 +683,6 @@ int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
 
 int32_t ekf_get_P(ekf_handle *h, double *P) {
     if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "get_P: null argument");
-    REQUIRE(h, h->cfg.world == 1, EKF_ERR_STATE, "get_P: a shard holds only its own tiles; use ekf_get_P_block per shard");
     int32_t rc = use_device(h);
     if (rc) return rc;
     const int64_t n = 3 + n_mm(h);
@@ -514,7 +716,6 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
     const int64_t n = 3 + n_mm(h);
     REQUIRE(h, r0 >= 0 && c0 >= 0 && nr >= 1 && nc >= 1 && r0 + nr <= n && c0 + nc <= n, EKF_ERR_INVALID_ARG,
             "get_P_block: block outside P");
-    REQUIRE(h, h->cfg.world == 1, EKF_ERR_STATE, "get_P_block: not available on a shard yet");
     int32_t rc = use_device(h);
     if (rc) return rc;
     double *d = nullptr;

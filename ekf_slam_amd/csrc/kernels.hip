@@ -45,7 +45,10 @@ __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, i
     if (r < 3 && c < 3) return st.prr[cur][3 * r + c];
     if (r < 3) return st.strip[cur][r * st.ldm + (c - 3)];
     if (c < 3) return st.strip[cur][c * st.ldm + (r - 3)];
-    return pmm_low<TS>((const TS *)st.tiles, st.tm, r - 3, c - 3);
+    int64_t rm = r - 3, cm = c - 3;
+    if (rm < cm) { const int64_t t = rm; rm = cm; cm = t; }
+    if (!st.tm.mine(rm >> st.tm.shift, cm >> st.tm.shift)) return NAN;     // held by another shard
+    return pmm_low<TS>((const TS *)st.tiles, st.tm, rm, cm);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -188,8 +191,40 @@ __device__ inline void solve_small(const double *pss, double z0, double z1, doub
         o.Kr[b][cc] = o.Gr[0][b] * o.Phi[cc] + o.Gr[1][b] * o.Phi[2 + cc];
 }
 
+// Sharded source of the landmark row-panel M = P(j:j+1, landmark columns): after the all-gather every
+// shard holds `world` slabs of `slab` doubles; the T-wide chunk k of M sits in the slab of shard
+// (tile_row(j) + k) mod world at local chunk k / world, interleaved (M(1,c), M(2,c)).
+struct PanelView {
+    const double *recv;
+    int64_t slab;       // doubles per shard slab
+    int64_t Ij;         // tile row of j
+    __device__ __forceinline__ double2 at(const TileMap &tm, int64_t c) const {
+        const int64_t k = c >> tm.shift;
+        const int64_t o = (Ij + k) % tm.world;
+        const int64_t e = o * slab + (((k / tm.world) << tm.shift) + (c & (tm.T - 1))) * 2;
+        return make_double2(recv[e], recv[e + 1]);
+    }
+};
+
+// Each shard copies the chunks of M it owns (canonical lower-triangle entries) into its send slab.
 template <typename TS>
-__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a) {
+__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, double *__restrict__ send,
+                                                     int64_t nchunks_local) {
+    const TileMap &tm = st.tm;
+    const TS *__restrict__ tiles = (const TS *)st.tiles;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // local column: kl * T + cc
+    if (e >= (nchunks_local << tm.shift)) return;
+    const int64_t Ij = j >> tm.shift;
+    const int64_t k0 = ((tm.rank - Ij) % tm.world + tm.world) % tm.world;   // first chunk owned by this shard
+    const int64_t kl = e >> tm.shift, cc = e & (tm.T - 1);
+    const int64_t c = ((k0 + kl * tm.world) << tm.shift) + cc;
+    double m0 = 0.0, m1 = 0.0;
+    if (c < n_mm) { m0 = pmm_low<TS>(tiles, tm, j, c); m1 = pmm_low<TS>(tiles, tm, j + 1, c); }
+    reinterpret_cast<double2 *>(send)[e] = make_double2(m0, m1);
+}
+
+template <typename TS, bool kSharded>
+__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv) {
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
     const int tid = threadIdx.x;
@@ -201,7 +236,15 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a) {
 
     if (tid < 9) pss[tid] = st.prr[cur][tid];
     else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
-    else if (tid < 19) { const int t = (tid - 15) >> 1, b = (tid - 15) & 1; pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b); }
+    else if (tid < 19) {
+        const int t = (tid - 15) >> 1, b = (tid - 15) & 1;     // canonical P(j+t, j+b)
+        if (kSharded) {
+            const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
+            pss[tid] = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
+        } else {
+            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
+        }
+    }
     else if (tid < 22) pss[tid] = x[tid - 19];
     else if (tid < 24) pss[tid] = x[3 + j + (tid - 22)];
     __syncthreads();
@@ -212,8 +255,9 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a) {
     const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
     if (c < a.n_mm) {
         // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part right)
-        const double m0 = pmm_low<TS>(tiles, st.tm, j, c);
-        const double m1 = pmm_low<TS>(tiles, st.tm, j + 1, c);
+        double m0, m1;
+        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
+        else { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
         const double s0 = strip[c], s1 = strip[ldm + c], s2 = strip[2 * ldm + c];
         double g[2];
         for (int r = 0; r < 2; ++r)
@@ -326,7 +370,11 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         double pss[24];
         for (int i = 0; i < 9; ++i) pss[i] = st.prr[cur][i];
         for (int t = 0; t < 3; ++t) for (int b = 0; b < 2; ++b) pss[9 + 2 * t + b] = strip[t * st.ldm + j + b];
-        for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b) pss[15 + 2 * t + b] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
+        // the 2x2 diagonal block lives in a diagonal tile; on another shard's tile the position cost is NaN
+        // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
+        const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
+        for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b)
+            pss[15 + 2 * t + b] = have_diag ? pmm_low<TS>(tiles, st.tm, j + t, j + b) : NAN;
         for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
         SmallSolve sol;
@@ -531,9 +579,40 @@ hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, h
 hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kBlock);
+    PanelView pv;
+    pv.recv = nullptr; pv.slab = 0; pv.Ij = 0;
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_gather<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a),
-        hipLaunchKernelGGL(k_gather<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a));
+        hipLaunchKernelGGL((k_gather<double, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv),
+        hipLaunchKernelGGL((k_gather<float, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv));
+    return hipGetLastError();
+}
+
+int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm) {
+    const int64_t nt = ekf_tiles_for(n_mm, tm.T);
+    const int64_t Ij = j >> tm.shift;
+    const int64_t k0 = ((tm.rank - Ij) % tm.world + tm.world) % tm.world;
+    return k0 >= nt ? 0 : (nt - k0 + tm.world - 1) / tm.world;
+}
+
+hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, double *send, int storage, hipStream_t s) {
+    const int64_t nloc = rowpanel_local_chunks(st.tm, j, n_mm);
+    if (nloc == 0) return hipSuccess;
+    const int64_t grid = cdiv(nloc * st.tm.T, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, send, nloc),
+        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, send, nloc));
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const double *recv, int64_t slab, int storage,
+                                 hipStream_t s) {
+    const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
+    const int64_t grid = cdiv(cols, kBlock);
+    PanelView pv;
+    pv.recv = recv; pv.slab = slab; pv.Ij = a.j >> st.tm.shift;
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL((k_gather<double, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv),
+        hipLaunchKernelGGL((k_gather<float, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv));
     return hipGetLastError();
 }
 

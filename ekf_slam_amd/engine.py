@@ -39,6 +39,7 @@ class Engine:
             else:
                 setattr(cfg, k, v)
         self.cfg = cfg
+        self._host_exchange = None
         self.h = ctypes.c_void_p()
         rc = self.lib.ekf_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != L.EKF_OK:
@@ -73,7 +74,34 @@ class Engine:
                                         _p(_vec(pos, 2)), float(signature)))
 
     def correct(self, z, R, idx0):
+        if self._host_exchange is not None:      # sharded, all-gather done by the host (torch.distributed)
+            self.correct_begin(z, R, idx0)
+            self._host_exchange(self)
+            self.correct_finish()
+            return
         self._check(self.lib.ekf_correct(self.h, _p(_vec(z[:2], 2)), _p(_colmajor(R).reshape(-1, order="F")), int(idx0)))
+
+    # ---- sharded correction, split so that the caller can run the all-gather (include/ekfslam.h, multi-GPU) ----
+    def correct_begin(self, z, R, idx0):
+        self._check(self.lib.ekf_correct_begin(self.h, _p(_vec(z[:2], 2)), _p(_colmajor(R).reshape(-1, order="F")),
+                                               int(idx0)))
+
+    def correct_finish(self):
+        self._check(self.lib.ekf_correct_finish(self.h))
+
+    def exchange_info(self):
+        send, recv = ctypes.c_void_p(), ctypes.c_void_p()
+        cnt, cap = ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.ekf_exchange_info(self.h, ctypes.byref(send), ctypes.byref(recv), ctypes.byref(cnt),
+                                               ctypes.byref(cap)))
+        return send.value, recv.value, int(cnt.value), int(cap.value)
+
+    def exchange_set_buffers(self, send_ptr, recv_ptr):
+        self._check(self.lib.ekf_exchange_set_buffers(self.h, ctypes.c_void_p(send_ptr), ctypes.c_void_p(recv_ptr)))
+
+    def comm_init(self, comm_id_bytes):
+        assert len(comm_id_bytes) == L.EKF_COMM_ID_BYTES
+        self._check(self.lib.ekf_comm_init(self.h, bytes(comm_id_bytes)))
 
     def associate(self, z, R, want_costs=False):
         is_new, idx = ctypes.c_int32(), ctypes.c_int64()

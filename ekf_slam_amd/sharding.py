@@ -1,0 +1,143 @@
+"""Multi-GPU plumbing around the sharded C ABI (include/ekfslam.h, section "multi-GPU").
+
+P is split over `world` shards: tile (I,J) of the landmark block lives on shard (I + J) mod world; x, s, the
+robot block and the robot/landmark strip are replicated.  The only data-path exchange is ONE all-gather per
+update-step of the 2 x 2N landmark row-panel (chunk k of T columns comes from shard (tile_row(j)+k) mod world).
+
+  * ``attach_communicator``  one process per GPU (torchrun): gives the handle a native RCCL communicator
+                             (ncclUniqueId from rank 0, broadcast through torch.distributed); if that fails it
+                             falls back to running the all-gather through torch.distributed itself.
+  * ``ShardGroup``           every shard of one filter driven from ONE host thread in one process (what a
+                             MATLAB host does; also how the sharded path is tested on a single GPU).
+  * ``owner`` / ``panel_source`` host-only views of the shard plan.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+
+
+def owner(world, I, J):
+    return int(L.lib().ekf_shard_owner(world, I, J))
+
+
+def slot(world, I, J):
+    return int(L.lib().ekf_shard_slot(world, I, J))
+
+
+def panel_source(world, tile_row_j, chunk):
+    o, k = ctypes.c_int32(), ctypes.c_int64()
+    rc = L.lib().ekf_shard_panel_source(world, tile_row_j, chunk, ctypes.byref(o), ctypes.byref(k))
+    if rc:
+        raise L.EkfError(rc, "ekf_shard_panel_source")
+    return int(o.value), int(k.value)
+
+
+def attach_communicator(engine, dist, torch, prefer="rccl"):
+    """Give a sharded Engine its exchange.  Returns the transport actually in use."""
+    world, rank = engine.cfg.world, engine.cfg.rank
+    if prefer == "rccl":
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        try:
+            buf = torch.zeros(L.EKF_COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+                rc = L.lib().ekf_comm_unique_id(raw)
+                if rc:
+                    raise L.EkfError(rc, "ekf_comm_unique_id")
+                buf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+            dist.broadcast(buf, src=0)
+            engine.comm_init(bytes(buf.cpu().numpy().tobytes()))
+        except Exception as ex:  # noqa: BLE001 -- any failure selects the torch transport on EVERY rank
+            print("[rank %d] native RCCL communicator unavailable (%s); using torch.distributed all_gather" % (rank, ex),
+                  flush=True)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return "rccl-native"
+        if engine.lib.ekf_last_error(engine.h):
+            pass
+    # host-run exchange over torch.distributed (RCCL underneath with backend "nccl"): the handle launches on
+    # torch's current stream so that the collective is ordered between extract and solve
+    _, _, _, cap = engine.exchange_info()
+    send = torch.zeros(cap, dtype=torch.float64, device="cuda")
+    recv = torch.zeros(cap * world, dtype=torch.float64, device="cuda")
+    engine.exchange_set_buffers(send.data_ptr(), recv.data_ptr())
+    engine.set_stream(torch.cuda.current_stream().cuda_stream)
+    engine._xchg_tensors = (send, recv)
+
+    def host_exchange(e):
+        _, _, cnt, _ = e.exchange_info()
+        dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
+
+    engine._host_exchange = host_exchange
+    return "torch.distributed"
+
+
+class ShardGroup:
+    """All `world` shards of ONE filter, driven by one host thread (devices[r] is the HIP device of shard r)."""
+
+    def __init__(self, world, devices=None, **engine_kw):
+        devices = devices if devices is not None else [0] * world
+        self.world = world
+        self.shards = [Engine(rank=r, world=world, device=devices[r], **engine_kw) for r in range(world)]
+        self._harr = (ctypes.c_void_p * world)(*[e.h for e in self.shards])
+        self.lib = self.shards[0].lib
+
+    def close(self):
+        for e in self.shards:
+            e.close()
+
+    @property
+    def N(self):
+        return self.shards[0].N
+
+    def predict(self, u):
+        for e in self.shards:
+            e.predict(u)
+
+    def append(self, u, R, pos, signature):
+        for e in self.shards:
+            e.append(u, R, pos, signature)
+
+    def correct(self, z, R, idx0):
+        for e in self.shards:
+            e.correct_begin(z, R, idx0)
+        rc = self.lib.ekf_exchange_local(self._harr, self.world)
+        if rc:
+            raise L.EkfError(rc, self.lib.ekf_last_error(self.shards[0].h).decode())
+        for e in self.shards:
+            e.correct_finish()
+
+    def associate(self, z, R):
+        res = [e.associate(z, R) for e in self.shards]
+        assert all(r == res[0] for r in res), "shards disagree on the association"
+        return res[0]
+
+    def set_state(self, x, P, s):
+        for e in self.shards:
+            e.set_state(x, P, s)
+
+    def load_lowrank_state(self, x, s, d, U):
+        for e in self.shards:
+            e.load_lowrank_state(x, s, d, U)
+
+    def get_x(self):
+        xs = [e.get_x() for e in self.shards]
+        for x in xs[1:]:
+            np.testing.assert_array_equal(x, xs[0])      # replicated state must be bit-identical
+        return xs[0]
+
+    def get_P(self):
+        """Merge the shards' views: each returns NaN for landmark-block entries it does not hold."""
+        P = self.shards[0].get_P()
+        for e in self.shards[1:]:
+            Q = e.get_P()
+            hole = np.isnan(P)
+            P[hole] = Q[hole]
+        return P
+
+    def digest(self):
+        return sum(e.digest() for e in self.shards)

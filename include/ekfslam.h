@@ -114,13 +114,41 @@ int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32
 int32_t ekf_measure(ekf_handle *h, const double *observed_LL, int64_t m, const double u[2],
                     const double *lm_index, const double *lm_loc, int64_t L);
 
+/* ---- multi-GPU: P split over `world` shards (cfg.rank / cfg.world), tile (I,J) on shard (I+J) mod world ----
+ * x, s, the robot block and the robot/landmark strip are replicated; predict, append and associate need no
+ * exchange.  A correction needs the 2 x 2N landmark row-panel P(j:j+1,:), whose T-wide chunk k lives on shard
+ * (tile_row(j) + k) mod world: one equal-count all-gather per update-step.  Three ways to run it:
+ *   (a) ekf_comm_init: the library owns an RCCL communicator (one process per GPU); ekf_correct / ekf_measure
+ *       then run extract -> ncclAllGather -> solve -> downdate on the handle's stream;
+ *   (b) ekf_correct_begin, the caller's own all-gather over the device buffers of ekf_exchange_info (e.g.
+ *       torch.distributed on buffers given through ekf_exchange_set_buffers), ekf_correct_finish;
+ *   (c) ekf_exchange_local: one host thread driving every shard of the filter in ONE process (the way a
+ *       MATLAB host would): begin on all handles, ekf_exchange_local, finish on all handles. */
+typedef struct ekf_comm_id { char internal[128]; } ekf_comm_id;   /* == ncclUniqueId */
+int32_t ekf_comm_unique_id(ekf_comm_id *id);                      /* rank 0 creates it, the host broadcasts it */
+int32_t ekf_comm_init(ekf_handle *h, const ekf_comm_id *id);      /* collective over all shards */
+int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx);
+int32_t ekf_correct_finish(ekf_handle *h);
+/* Device pointers of the exchange: send slab (*count doubles valid for the pending correction) and receive
+ * area (world slabs of *count doubles, slab r from shard r); *count_capacity = largest count at capacity. */
+int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity);
+/* Use caller-owned device buffers (>= count_capacity and world * count_capacity doubles); NULL restores the own ones. */
+int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv);
+int32_t ekf_exchange_local(ekf_handle **shards, int32_t world);
+/* Host-only descriptions of the shard plan (no GPU needed): owner of tile (I,J); its slot in the owner's tile
+ * store; which shard / local chunk supplies chunk `chunk` of the row-panel of a landmark in tile row tile_row_j. */
+int32_t ekf_shard_owner(int32_t world, int64_t I, int64_t J);
+int64_t ekf_shard_slot(int32_t world, int64_t I, int64_t J);
+int32_t ekf_shard_panel_source(int32_t world, int64_t tile_row_j, int64_t chunk, int32_t *owner, int64_t *local_chunk);
+
 /* ---- state access (the reference's public properties x, P, Q, s; EKF_SLAM.m:6-9) ---- */
 int32_t ekf_num_landmarks(ekf_handle *h, int64_t *N);
 int32_t ekf_get_x(ekf_handle *h, double *x /* 3+2N */);
 int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n);
 int32_t ekf_get_s(ekf_handle *h, double *s /* N */);
 int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N);
-/* Dense n x n column-major P.  set_P stores the lower triangle (P is a covariance: symmetric). */
+/* Dense n x n column-major P.  set_P stores the lower triangle (P is a covariance: symmetric).  On a shard
+ * (world > 1) get_P / get_P_block return NaN for landmark-block entries held by another shard. */
 int32_t ekf_get_P(ekf_handle *h, double *P);
 int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n);
 /* P(r0:r0+nr-1, c0:c0+nc-1) into out (nr x nc column-major): what plot() reads (EKF_SLAM.m:180,205). */

@@ -1,0 +1,128 @@
+"""GPU: the sharded correction path (tile (I,J) on shard (I+J) mod world; one all-gather of the landmark
+row-panel per update-step) against the CPU oracle and against the unsharded HIP path.
+
+Only one GPU is available to the tests, so `world` shards of one filter live on that GPU in ONE process and the
+exchange is ekf_exchange_local (transport (c) of include/ekfslam.h); the RCCL and torch.distributed transports
+are exercised with world == 1 (a 1-rank communicator), which runs the same extract -> all-gather -> solve code."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _state(N, seed):
+    rng = np.random.default_rng(seed)
+    n = 3 + 2 * N
+    x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N)])
+    U = rng.normal(0, 0.05, size=(n, 6))
+    d = rng.uniform(0.01, 0.1, size=n)
+    return x, np.diag(d) + U @ U.T, np.arange(1, N + 1.0), d, U
+
+
+@pytest.mark.parametrize("world,tile", [(2, 16), (3, 16), (4, 32), (8, 16), (2, 64)])
+def test_shard_group_matches_oracle_and_unsharded(world, tile, oracle_lib):
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    from oracle.ekf_structured import StructuredEKF
+    N = 150
+    x, P, s, _, _ = _state(N, 21)
+    g = ShardGroup(world, capacity=N + 8, tile=tile)
+    one = Engine(capacity=N + 8, tile=tile)
+    ref = StructuredEKF(N + 8, "known")
+    g.set_state(x, P, s); one.set_state(x, P, s); ref.set_state(x, P, s)
+    assert rel_err(g.get_P(), P) == 0.0
+    rng = np.random.default_rng(4)
+    seq = [0, 3, N // 2, N - 1, 9, 77]
+    for step, idx0 in enumerate(seq):
+        u = [0.1, 3.0]
+        g.predict(u); one.predict(u); ref.predict(u)
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        g.correct(z, R, idx0); one.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+        if step % 2 == 1:                         # grow the map while sharded (streaming append)
+            pos = rng.uniform(-5, 5, 2)
+            sig = g.N + 1
+            g.append(u, R, pos, sig); one.append(u, R, pos, sig); ref.append(u, R, pos, sig)
+            g.correct(z, R, g.N - 1); one.correct(z, R, one.N - 1); ref.correct(z, R, ref.N)
+    Pg, Po = g.get_P(), one.get_P()
+    assert not np.isnan(Pg).any()
+    assert rel_err(g.get_x(), ref.x) < REL and rel_err(Pg, ref.P) < REL
+    # same kernels, same arithmetic: sharding must not change a single bit
+    np.testing.assert_array_equal(Pg, Po)
+    np.testing.assert_array_equal(g.get_x(), one.get_x())
+    np.testing.assert_allclose(g.digest(), one.digest(), rtol=1e-12)
+    g.close(); one.close()
+
+
+def test_shard_group_uc_association(oracle_lib):
+    from ekf_slam_amd.sharding import ShardGroup
+    from oracle.ekf_structured import StructuredEKF
+    N = 90
+    x, P, s, _, _ = _state(N, 23)
+    g = ShardGroup(3, mode="uc", capacity=N, tile=16)
+    ref = StructuredEKF(N, "uc")
+    g.set_state(x, P, s); ref.set_state(x, P, s)
+    R = np.diag([1.0, 50.0])
+    for sig in (5.0, 90.0, 91.0):
+        new_g, idx_g = g.associate([7.0, 123.0, sig], R)
+        new_r, idx_r = ref.associate([7.0, 123.0, sig], R)
+        assert (new_g, idx_g + 1) == (new_r, idx_r)
+    g.close()
+
+
+_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+os.environ["EKF_FORCE_SHARDED"] = "1"
+import ctypes
+from ekf_slam_amd import Engine, _lib as L
+rng = np.random.default_rng(31)
+N = 120; n = 3 + 2 * N
+x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, 2 * N)])
+U = rng.normal(0, 0.05, (n, 6)); P = np.diag(rng.uniform(0.01, 0.1, n)) + U @ U.T
+s = np.arange(1, N + 1.0)
+mode = sys.argv[1]
+e = Engine(capacity=N, tile=32)
+os.environ["EKF_FORCE_SHARDED"] = "0"
+ref = Engine(capacity=N, tile=32)
+e.set_state(x, P, s); ref.set_state(x, P, s)
+if mode == "rccl":
+    raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+    assert L.lib().ekf_comm_unique_id(raw) == 0
+    e.comm_init(raw.raw)
+    transport = "rccl-native"
+else:
+    import torch, torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29591")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from ekf_slam_amd.sharding import attach_communicator
+    transport = attach_communicator(e, dist, torch, prefer=mode)
+for idx0 in (0, 50, 119, 7):
+    z = [rng.uniform(1, 30), rng.uniform(1, 359)]; R = np.diag([z[0] * .01, z[1] * 5.0])
+    e.predict([0.1, 3.0]); ref.predict([0.1, 3.0])
+    e.correct(z, R, idx0); ref.correct(z, R, idx0)
+np.testing.assert_array_equal(e.get_P(), ref.get_P())
+np.testing.assert_array_equal(e.get_x(), ref.get_x())
+print("TRANSPORT", transport)
+"""
+
+
+@pytest.mark.parametrize("mode,expect", [("rccl", "rccl-native"), ("torch", "torch.distributed")])
+def test_one_rank_communicators(mode, expect):
+    """Real RCCL communicator / torch.distributed (nccl) all-gather with a single rank, in a child process."""
+    out = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}, mode], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "TRANSPORT " + expect in out.stdout
