@@ -13,6 +13,8 @@
 //   k_associate  per-landmark phi_k, Mahalanobis + signature     Correspondence.m:49-87
 #include "kernels.h"
 
+#include <cstdlib>
+
 #include "device_math.h"
 
 namespace {
@@ -290,33 +292,38 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 // rank-2 downdate of the landmark block:  tile(I,J)[r][c] -= K(I*T+r,:) . G(:,J*T+c)
 //
 // The HBM-bound kernel.  Every unique entry of P is read once and written once (w*n*(n+1) bytes per
-// launch); K and G (2 x n each) stay in L2.  A 256-thread workgroup walks owned tiles from a work list;
-// inside a tile each lane owns one 16-byte column pair and strides over the rows, so each wavefront
-// load/store instruction moves 1 KiB of contiguous tile memory, and the lane's four G values stay in
-// registers for the whole tile.
+// launch); K and G (2 x n each) stay in L2.  A work item is a (tile, slab) pair: kSlab rows of one owned
+// tile.  Inside it each lane owns one 16-byte column pair, so every wavefront load/store instruction moves
+// 1 KiB of contiguous tile memory; the lane's four G values and the row's two K values come from L2.
 // ---------------------------------------------------------------------------------------------------
 template <typename TS> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
-template <typename TS, int T>
+template <typename TS, int T, int kSlab>
 __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, const int2 *__restrict__ work,
                                                      int64_t nwork, const double *__restrict__ Ki,
                                                      const double *__restrict__ Gi, TileMap tm) {
+    // kSlab = rows of a tile one workgroup pass handles (T = whole tile); a work item is (tile, slab)
     using V2 = typename Vec2<TS>::type;
     constexpr int kPairsPerRow = T / 2;
     constexpr int kRowsPerPass = kBlock / kPairsPerRow;
-    constexpr int kPasses = (T + kRowsPerPass - 1) / kRowsPerPass;
+    constexpr int kSlabsPerTile = T / kSlab;
+    constexpr int kPasses = (kSlab + kRowsPerPass - 1) / kRowsPerPass;
     constexpr int kUnroll = kPasses < 8 ? kPasses : 8;
+    constexpr bool kExact = kRowsPerPass * kPasses == kSlab;
     const int tid = threadIdx.x;
     const int cp = tid % kPairsPerRow;       // column pair inside the tile
-    const int r0 = tid / kPairsPerRow;       // first row of this lane
-    for (int64_t w = blockIdx.x; w < nwork; w += gridDim.x) {
+    const int r0 = tid / kPairsPerRow;       // first row of this lane inside the slab
+    const int64_t nitems = nwork * kSlabsPerTile;
+    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int64_t w = it / kSlabsPerTile;
+        const int slab = (int)(it - w * kSlabsPerTile);
         const int2 ij = work[w];
-        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y);
+        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)slab * kSlab * T;
         const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gi) + ((int64_t)ij.y * T + 2 * cp);
         const double2 ga = g2[0], gb = g2[1];                      // (G1,G2) at columns 2cp and 2cp+1
-        const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Ki) + (int64_t)ij.x * T;
+        const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Ki) + ((int64_t)ij.x * T + slab * kSlab);
 #pragma unroll 1
         for (int p0 = 0; p0 < kPasses; p0 += kUnroll) {
             V2 v[kUnroll];
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
 #pragma unroll
             for (int p = 0; p < kUnroll; ++p) {
                 const int r = r0 + (p0 + p) * kRowsPerPass;
-                if (kRowsPerPass * kPasses == T || r < T) {
+                if (kExact || r < kSlab) {
                     v[p] = *reinterpret_cast<const V2 *>(tp + r * T + 2 * cp);
                     k[p] = k2[r];
                 }
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
 #pragma unroll
             for (int p = 0; p < kUnroll; ++p) {
                 const int r = r0 + (p0 + p) * kRowsPerPass;
-                if (kRowsPerPass * kPasses == T || r < T) {
+                if (kExact || r < kSlab) {
                     V2 o;
                     o.x = (TS)((double)v[p].x - (k[p].x * ga.x + k[p].y * ga.y));
                     o.y = (TS)((double)v[p].y - (k[p].x * gb.x + k[p].y * gb.y));
@@ -616,25 +623,38 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
     return hipGetLastError();
 }
 
-template <typename TS>
-static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, hipStream_t s) {
-    if (nwork <= 0) return hipSuccess;
-    int64_t grid = nwork;
+template <typename TS, int T, int kSlab>
+static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, hipStream_t s) {
+    int64_t grid = nwork * (T / kSlab);
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    TS *tiles = (TS *)st.tiles;
-    switch (st.tm.T) {
-        case 16:  hipLaunchKernelGGL((k_downdate<TS, 16>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
-        case 32:  hipLaunchKernelGGL((k_downdate<TS, 32>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
-        case 64:  hipLaunchKernelGGL((k_downdate<TS, 64>),  dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
-        case 128: hipLaunchKernelGGL((k_downdate<TS, 128>), dim3((unsigned)grid), dim3(kBlock), 0, s, tiles, work, nwork, st.Ki, st.Gi, st.tm); break;
-        default: return hipErrorInvalidValue;
-    }
+    hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
+                       st.Ki, st.Gi, st.tm);
     return hipGetLastError();
 }
 
+// Default granularity: ONE pass per workgroup (each lane loads, updates and stores exactly one 16-byte column
+// pair; a workgroup covers 4 KiB of a tile).  Measured on MI355X at 10k landmarks (profiles/round1_tuning.md):
+// 1 pass 6.06 TB/s, 2 passes 5.62, 4 passes 5.58, whole 64x64 tile (8 passes) 5.49; persistent grids
+// (1024-8192 workgroups) and nontemporal loads/stores made no difference or lost 3-5 %.
+// EKF_DOWNDATE_SLAB (rows per workgroup) and EKF_DOWNDATE_GRID (grid cap) remain as tuning hooks.
+template <typename TS>
+static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, int slab, hipStream_t s) {
+    if (nwork <= 0) return hipSuccess;
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, grid_cap, s)
+    switch (st.tm.T) {
+        case 16: EKF_DD(16, 16);
+        case 32: if (slab == 32) EKF_DD(32, 32); EKF_DD(32, 16);
+        case 64: if (slab == 64) EKF_DD(64, 64); if (slab == 32) EKF_DD(64, 32); if (slab == 16) EKF_DD(64, 16); EKF_DD(64, 8);
+        case 128: if (slab == 128) EKF_DD(128, 128); if (slab == 32) EKF_DD(128, 32); if (slab == 8) EKF_DD(128, 8); EKF_DD(128, 4);
+        default: return hipErrorInvalidValue;
+    }
+#undef EKF_DD
+}
+
 hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int storage, int grid_cap, hipStream_t s) {
-    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, grid_cap, s)
-                        : launch_downdate_t<float>(st, work, nwork, grid_cap, s);
+    static const int slab = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
+    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, grid_cap, slab, s)
+                        : launch_downdate_t<float>(st, work, nwork, grid_cap, slab, s);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
