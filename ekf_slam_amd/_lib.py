@@ -43,6 +43,7 @@ SIGNATURES = {
     "ekf_last_error": (ctypes.c_char_p, [_vp]),
     "ekf_set_stream": (_i32, [_vp, _vp]),
     "ekf_sync": (_i32, [_vp]),
+    "ekf_set_params": (_i32, [_vp, _d, _dp, _d, _d, _d]),
     "ekf_predict": (_i32, [_vp, _dp]),
     "ekf_motion_model": (_i32, [_dp, _i64, _dp, _dp, _dp]),
     "ekf_append": (_i32, [_vp, _dp, _dp, _dp, _d]),

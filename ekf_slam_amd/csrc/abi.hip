@@ -461,6 +461,13 @@ int32_t ekf_sync(ekf_handle *h) {
     return EKF_OK;
 }
 
+int32_t ekf_set_params(ekf_handle *h, double C, const double Rc[2], double s_cost, double s_thresh, double w_pos) {
+    if (!h || !Rc) return fail(h, EKF_ERR_INVALID_ARG, "set_params: null argument");
+    h->cfg.C = C; h->cfg.Rc[0] = Rc[0]; h->cfg.Rc[1] = Rc[1];
+    h->cfg.s_cost = s_cost; h->cfg.s_thresh = s_thresh; h->cfg.w_pos = w_pos;
+    return EKF_OK;
+}
+
 int32_t ekf_predict(ekf_handle *h, const double u[2]) {
     if (!h || !u) return fail(h, EKF_ERR_INVALID_ARG, "predict: null argument");
     int32_t rc = use_device(h);

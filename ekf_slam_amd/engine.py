@@ -122,6 +122,16 @@ class Engine:
         self._check(self.lib.ekf_measure(self.h, _p(obs.reshape(-1, order="F")), obs.shape[0], _p(_vec(u, 2)),
                                          _p(idx), _p(loc.reshape(-1, order="F")), idx.size))
 
+    def set_params(self, C=None, Rc=None, s_cost=None, s_thresh=None, w_pos=None):
+        c = self.cfg
+        if C is not None: c.C = float(C)
+        if Rc is not None: c.Rc[0], c.Rc[1] = float(Rc[0]), float(Rc[1])
+        if s_cost is not None: c.s_cost = float(s_cost)
+        if s_thresh is not None: c.s_thresh = float(s_thresh)
+        if w_pos is not None: c.w_pos = float(w_pos)
+        rc2 = (ctypes.c_double * 2)(c.Rc[0], c.Rc[1])
+        self._check(self.lib.ekf_set_params(self.h, c.C, rc2, c.s_cost, c.s_thresh, c.w_pos))
+
     def sync(self):
         self._check(self.lib.ekf_sync(self.h))
 

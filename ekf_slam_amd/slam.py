@@ -64,9 +64,17 @@ class _EkfBase:
     def C(self):
         return self._e.cfg.C
 
+    @C.setter
+    def C(self, v):
+        self._e.set_params(C=v)
+
     @property
     def Rc(self):
         return [self._e.cfg.Rc[0], self._e.cfg.Rc[1]]
+
+    @Rc.setter
+    def Rc(self, v):
+        self._e.set_params(Rc=v)
 
     @property
     def s_cost(self):

@@ -83,6 +83,9 @@ const char *ekf_last_error(const ekf_handle *h);
  * handle's own stream. */
 int32_t     ekf_set_stream(ekf_handle *h, void *hip_stream);
 int32_t     ekf_sync(ekf_handle *h);
+/* The reference's tunables are public properties that may be reassigned at any time (EKF_SLAM.m:12-16):
+ * update C, Rc, s_cost, s_thresh, w_pos of a live handle. */
+int32_t     ekf_set_params(ekf_handle *h, double C, const double Rc[2], double s_cost, double s_thresh, double w_pos);
 
 /* ---- hot path ---- */
 /* predict(h,u)  EKF_SLAM.m:40-51 (EKF_SLAM_UC.m:42-53): u = [dD, dTheta_deg]. */

@@ -1,0 +1,92 @@
+/*
+ * MEX gateway: MATLAB -> C ABI (include/ekfslam.h) -> HIP.   NOT COMPILED OR RUN IN THIS REPOSITORY'S IMAGE
+ * (no MATLAB / mex.h there); build on a MATLAB host with
+ *     mex -I../include ekfslam_mex.c -L../ekf_slam_amd -lekfslam
+ *
+ * One entry point, string command first:   out = ekfslam_mex('command', handle, args...)
+ * The handle travels as a uint64 scalar.  MATLAB's 1-based landmark indices are converted to the ABI's
+ * 0-based ones here.  Any non-zero status becomes mexErrMsgIdAndTxt('ekfslam:status', ...), so the .m classes
+ * see MATLAB errors exactly where the reference's own code would raise them.
+ */
+#include <string.h>
+
+#include "ekfslam.h"
+#include "mex.h"
+
+static ekf_handle *H(const mxArray *a) { return (ekf_handle *)(uintptr_t)(*(uint64_t *)mxGetData(a)); }
+
+static void check(ekf_handle *h, int32_t rc) {
+    if (rc != EKF_OK)
+        mexErrMsgIdAndTxt("ekfslam:status", "%s: %s", ekf_status_string(rc), h ? ekf_last_error(h) : "");
+}
+
+static int64_t nstate(ekf_handle *h) { int64_t N; check(h, ekf_num_landmarks(h, &N)); return 3 + 2 * N; }
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
+    char cmd[32];
+    if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("ekfslam:usage", "command string expected");
+    (void)nlhs;
+
+    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile]) */
+        ekf_config cfg;
+        ekf_handle *h = NULL;
+        check(NULL, ekf_config_default(&cfg, (int32_t)mxGetScalar(prhs[1])));
+        cfg.capacity_landmarks = (int64_t)mxGetScalar(prhs[2]);
+        if (nrhs > 3) cfg.tile = (int32_t)mxGetScalar(prhs[3]);
+        int32_t rc = ekf_create(&cfg, &h);
+        if (rc != EKF_OK) { const char *m = h ? ekf_last_error(h) : ""; mexErrMsgIdAndTxt("ekfslam:status", "%s: %s", ekf_status_string(rc), m); }
+        plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+        *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)h;
+        mexLock();
+        return;
+    }
+    ekf_handle *h = H(prhs[1]);
+    if (!strcmp(cmd, "destroy")) { ekf_destroy(h); mexUnlock(); return; }
+    if (!strcmp(cmd, "set_params")) {             /* (h, C, Rc, s_cost, s_thresh, w_pos) */
+        check(h, ekf_set_params(h, mxGetScalar(prhs[2]), mxGetPr(prhs[3]), mxGetScalar(prhs[4]), mxGetScalar(prhs[5]), mxGetScalar(prhs[6])));
+        return;
+    }
+    if (!strcmp(cmd, "predict")) { check(h, ekf_predict(h, mxGetPr(prhs[2]))); return; }
+    if (!strcmp(cmd, "append"))  { check(h, ekf_append(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetScalar(prhs[5]))); return; }
+    if (!strcmp(cmd, "correct")) { check(h, ekf_correct(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetScalar(prhs[4]) - 1)); return; }
+    if (!strcmp(cmd, "associate")) {              /* [newLL, index] = ... (z 1x3, R 2x2) ; index 1-based */
+        int32_t is_new; int64_t idx;
+        check(h, ekf_associate(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), &is_new, &idx, NULL, NULL));
+        plhs[0] = mxCreateLogicalScalar(is_new != 0);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)(idx + 1));
+        return;
+    }
+    if (!strcmp(cmd, "measure")) {                /* (h, observed_LL m x 3, u, lm_index L x 1, lm_loc L x 2) */
+        check(h, ekf_measure(h, mxGetPr(prhs[2]), (int64_t)mxGetM(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]),
+                             mxGetPr(prhs[5]), (int64_t)mxGetNumberOfElements(prhs[4])));
+        return;
+    }
+    if (!strcmp(cmd, "get_x")) { int64_t n = nstate(h); plhs[0] = mxCreateDoubleMatrix(1, (mwSize)n, mxREAL); check(h, ekf_get_x(h, mxGetPr(plhs[0]))); return; }
+    if (!strcmp(cmd, "get_P")) { int64_t n = nstate(h); plhs[0] = mxCreateDoubleMatrix((mwSize)n, (mwSize)n, mxREAL); check(h, ekf_get_P(h, mxGetPr(plhs[0]))); return; }
+    if (!strcmp(cmd, "get_s")) { int64_t n = (nstate(h) - 3) / 2; plhs[0] = mxCreateDoubleMatrix((mwSize)n, 1, mxREAL); check(h, ekf_get_s(h, mxGetPr(plhs[0]))); return; }
+    if (!strcmp(cmd, "get_Q")) { int64_t n = nstate(h); double q[9]; check(h, ekf_get_Q(h, q));
+        plhs[0] = mxCreateDoubleMatrix((mwSize)n, (mwSize)n, mxREAL);      /* zeros(size(P)) with the 3x3 block */
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) mxGetPr(plhs[0])[c * n + r] = q[3 * c + r];
+        return; }
+    if (!strcmp(cmd, "get_P_block")) {            /* (h, r0, c0, nr, nc), 1-based corner */
+        mwSize nr = (mwSize)mxGetScalar(prhs[4]), nc = (mwSize)mxGetScalar(prhs[5]);
+        plhs[0] = mxCreateDoubleMatrix(nr, nc, mxREAL);
+        check(h, ekf_get_P_block(h, (int64_t)mxGetScalar(prhs[2]) - 1, (int64_t)mxGetScalar(prhs[3]) - 1, nr, nc, mxGetPr(plhs[0])));
+        return;
+    }
+    if (!strcmp(cmd, "set_state")) {              /* (h, x, P, s) */
+        check(h, ekf_set_x(h, mxGetPr(prhs[2]), (int64_t)mxGetNumberOfElements(prhs[2])));
+        check(h, ekf_set_s(h, mxGetPr(prhs[4]), (int64_t)mxGetNumberOfElements(prhs[4])));
+        check(h, ekf_set_P(h, mxGetPr(prhs[3]), (int64_t)mxGetM(prhs[3])));
+        return;
+    }
+    if (!strcmp(cmd, "f")) {                      /* [x_new, F] = ekfslam_mex('f', [], x, u): pure host function */
+        mwSize n = mxGetNumberOfElements(prhs[2]);
+        plhs[0] = mxCreateDoubleMatrix(1, n, mxREAL);
+        mxArray *F = mxCreateDoubleMatrix(n, n, mxREAL);
+        check(NULL, ekf_motion_model(mxGetPr(prhs[2]), (int64_t)n, mxGetPr(prhs[3]), mxGetPr(plhs[0]), mxGetPr(F)));
+        if (nlhs > 1) plhs[1] = F; else mxDestroyArray(F);
+        return;
+    }
+    mexErrMsgIdAndTxt("ekfslam:usage", "unknown command '%s'", cmd);
+}
