@@ -30,7 +30,7 @@ class EkfConfig(ctypes.Structure):
     """struct ekf_config (include/ekfslam.h)."""
     _fields_ = [("C", _d), ("Rc", _d * 2), ("s_cost", _d), ("s_thresh", _d), ("w_pos", _d),
                 ("capacity_landmarks", _i64), ("mode", _i32), ("storage", _i32), ("device", _i32),
-                ("tile", _i32), ("rank", _i32), ("world", _i32), ("reserved", _i32 * 8)]
+                ("tile", _i32), ("rank", _i32), ("world", _i32), ("batch", _i32), ("reserved", _i32 * 7)]
 
 
 # name -> (restype, argtypes); every symbol of include/ekfslam.h
@@ -43,6 +43,8 @@ SIGNATURES = {
     "ekf_last_error": (ctypes.c_char_p, [_vp]),
     "ekf_set_stream": (_i32, [_vp, _vp]),
     "ekf_sync": (_i32, [_vp]),
+    "ekf_flush": (_i32, [_vp]),
+    "ekf_pending": (_i32, [_vp, ctypes.POINTER(_i32)]),
     "ekf_set_params": (_i32, [_vp, _d, _dp, _d, _d, _d]),
     "ekf_predict": (_i32, [_vp, _dp]),
     "ekf_motion_model": (_i32, [_dp, _i64, _dp, _dp, _dp]),

@@ -64,6 +64,8 @@ struct ekf_handle {
     int32_t T = 64;
     int32_t storage = 0;
     int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
+    int32_t batch = 1;     // max pending rank-2 pairs
+    int32_t npend = 0;     // pending pairs (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
     DevState st;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // work list of owned lower-triangle tiles for the active tile rows
@@ -169,6 +171,19 @@ void colmajor2(const double R[4], double &r00, double &r01, double &r10, double 
     r00 = R[0]; r10 = R[1]; r01 = R[2]; r11 = R[3];
 }
 
+// apply the pending pairs to the tiles: ONE pass over P for npend update-steps
+int32_t flush_pending(ekf_handle *h) {
+    if (h->npend == 0) return EKF_OK;
+    int32_t rc = refresh_work(h);
+    if (rc) return rc;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
+        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->npend, h->storage, h->grid_cap, h->stream));
+    }
+    h->npend = 0;
+    return EKF_OK;
+}
+
 int32_t do_predict(ekf_handle *h, const double u[2]) {
     PredictArgs a;
     a.u0 = u[0]; a.u1 = u[1]; a.C = h->cfg.C; a.n_mm = n_mm(h); a.cur = h->cur;
@@ -208,9 +223,9 @@ int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64
     CorrectArgs &a = h->pending_args;
     a.z0 = z[0]; a.z1 = z[1];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur;
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
     h->slab = slab_for(h, a.n_mm);
-    HIPCHK(h, launch_rowpanel(h->st, a.j, a.n_mm, h->send, h->storage, h->stream));
+    HIPCHK(h, launch_rowpanel(h->st, a.j, a.n_mm, h->npend, h->send, h->storage, h->stream));
     h->pending = true;
     return EKF_OK;
 }
@@ -223,11 +238,8 @@ int32_t correct_finish(ekf_handle *h) {
         HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, h->recv, h->slab, h->storage, h->stream));
     }
     h->cur ^= 1;
-    {
-        TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
-        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->storage, h->grid_cap, h->stream));
-    }
-    return EKF_OK;
+    h->npend += 1;
+    return h->npend >= h->batch ? flush_pending(h) : EKF_OK;
 }
 
 int32_t exchange_rccl(ekf_handle *h) {
@@ -253,17 +265,14 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     CorrectArgs a;
     a.z0 = z[0]; a.z1 = z[1];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur;
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         HIPCHK(h, launch_gather(h->st, a, h->storage, h->stream));
     }
     h->cur ^= 1;
-    {
-        TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
-        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->storage, h->grid_cap, h->stream));
-    }
-    return EKF_OK;
+    h->npend += 1;
+    return h->npend >= h->batch ? flush_pending(h) : EKF_OK;
 }
 
 int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
@@ -275,7 +284,7 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
     a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
-    a.N = h->N; a.cur = h->cur;
+    a.N = h->N; a.cur = h->cur; a.npend = h->npend;
     {
         TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
         HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_decision, h->storage,
@@ -347,6 +356,7 @@ int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
     cfg->tile = 0;
     cfg->rank = 0;
     cfg->world = 1;
+    cfg->batch = 1;
     return EKF_OK;
 }
 
@@ -359,6 +369,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->capacity_landmarks < 1 || cfg->rank < 0 || cfg->rank >= world) return EKF_ERR_INVALID_ARG;
     if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
     if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;
+    if (cfg->batch < 0 || cfg->batch > 1024) return EKF_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return EKF_ERR_NO_DEVICE;
@@ -394,8 +405,11 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         h->st.tiles = tiles;
     }
     HIPCHK(h, dalloc(h, &h->st.s, (size_t)h->cap));
-    HIPCHK(h, dalloc(h, &h->st.Gi, (size_t)(2 * ldm)));
-    HIPCHK(h, dalloc(h, &h->st.Ki, (size_t)(2 * ldm)));
+    h->batch = cfg->batch < 1 ? 1 : cfg->batch;
+    h->cfg.batch = h->batch;
+    h->st.pair_stride = 2 * ldm;
+    HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->batch));
+    HIPCHK(h, dalloc(h, &h->st.Kp, (size_t)(2 * ldm) * h->batch));
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
     HIPCHK(h, dalloc(h, &h->d_partial, (size_t)((h->cap + kAssocBlock - 1) / kAssocBlock)));
@@ -458,6 +472,19 @@ int32_t ekf_sync(ekf_handle *h) {
     int32_t rc = use_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return EKF_OK;
+}
+
+int32_t ekf_flush(ekf_handle *h) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    REQUIRE(h, !h->pending, EKF_ERR_STATE, "flush: a sharded correction is between begin and finish");
+    int32_t rc = use_device(h);
+    return rc ? rc : flush_pending(h);
+}
+
+int32_t ekf_pending(ekf_handle *h, int32_t *npending) {
+    if (!h || !npending) return EKF_ERR_INVALID_ARG;
+    *npending = h->npend;
     return EKF_OK;
 }
 
@@ -663,6 +690,12 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     REQUIRE(h, n >= 3 && (n - 3) % 2 == 0 && (n - 3) / 2 <= h->cap, EKF_ERR_INVALID_ARG, "set_x: bad length");
     int32_t rc = use_device(h);
     if (rc) return rc;
+    rc = flush_pending(h);     // pending pairs belong to the old state
+    if (rc) return rc;
+    if ((n - 3) / 2 < h->N) {  // shrinking the map: pair slots must read as zero beyond the active columns
+        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+    }
     h->N = (n - 3) / 2;
     HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -692,6 +725,8 @@ int32_t ekf_get_P(ekf_handle *h, double *P) {
     if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "get_P: null argument");
     int32_t rc = use_device(h);
     if (rc) return rc;
+    rc = flush_pending(h);
+    if (rc) return rc;
     const int64_t n = 3 + n_mm(h);
     double *dense = nullptr;
     HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
@@ -708,6 +743,7 @@ int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
     REQUIRE(h, n == 3 + n_mm(h), EKF_ERR_INVALID_ARG, "set_P: n must equal length(x) (set x first)");
     int32_t rc = use_device(h);
     if (rc) return rc;
+    h->npend = 0;              // the whole covariance is replaced
     double *dense = nullptr;
     HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
     hipError_t e = hipMemcpyAsync(dense, P, (size_t)(n * n) * 8, hipMemcpyHostToDevice, h->stream);
@@ -724,6 +760,8 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
     REQUIRE(h, r0 >= 0 && c0 >= 0 && nr >= 1 && nc >= 1 && r0 + nr <= n && c0 + nc <= n, EKF_ERR_INVALID_ARG,
             "get_P_block: block outside P");
     int32_t rc = use_device(h);
+    if (rc) return rc;
+    rc = flush_pending(h);
     if (rc) return rc;
     double *d = nullptr;
     HIPCHK(h, hipMalloc((void **)&d, (size_t)(nr * nc) * 8));
@@ -752,7 +790,12 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     int32_t rc = use_device(h);
     if (rc) return rc;
     const int64_t n = 3 + 2 * N;
+    if (N < h->N) {
+        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+    }
     h->N = N;
+    h->npend = 0;              // the whole state is replaced
     rc = refresh_work(h);
     if (rc) return rc;
     double *dd = nullptr, *dU = nullptr;
@@ -773,6 +816,8 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
 int32_t ekf_P_digest(ekf_handle *h, double out[3]) {
     if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "P_digest: null argument");
     int32_t rc = use_device(h);
+    if (rc) return rc;
+    rc = flush_pending(h);
     if (rc) return rc;
     rc = refresh_work(h);
     if (rc) return rc;

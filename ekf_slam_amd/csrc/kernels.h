@@ -14,8 +14,12 @@ struct DevState {
     double *strip[2];  // P(1:3, 4:end): 3 rows of ldm
     void   *tiles;     // local tile store of the landmark block (double or float)
     double *s;         // signatures, cap
-    double *Gi;        // 2*ldm: G = H_s P(S,:) over landmark columns, interleaved (G(1,c), G(2,c))
-    double *Ki;        // 2*ldm: K rows over landmark rows, interleaved (K(r,1), K(r,2))
+    // Pending rank-2 pairs: slot i holds G_i = H_s P(S,:) over landmark columns, interleaved (G(1,c), G(2,c)),
+    // and K_i over landmark rows, interleaved (K(r,1), K(r,2)); slots are pair_stride doubles apart.  The tiles
+    // hold P_base; the live landmark block is P_base - sum_i K_i G_i (applied in slot order).
+    double *Gp;
+    double *Kp;
+    int64_t pair_stride;   // 2 * ldm
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
     int64_t ldm;       // strip leading dimension = landmark-block capacity rounded up to T
     TileMap tm;
@@ -27,6 +31,7 @@ struct CorrectArgs {
     int64_t j;                // landmark-block row of the corrected landmark (2*idx)
     int64_t n_mm;             // active landmark-block size (2N)
     int32_t cur;
+    int32_t npend;            // pending pairs before this correction; its own pair goes to slot npend
 };
 
 struct PredictArgs {
@@ -49,6 +54,7 @@ struct AssocArgs {
     double s_cost, s_thresh, w_pos;
     int64_t N;
     int32_t cur;
+    int32_t npend;
 };
 
 struct AssocDecision {        // written by the device, read back by the host
@@ -67,11 +73,12 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, 
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
 int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
-hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, double *send, int storage, hipStream_t s);
+hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s);
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const double *recv, int64_t slab, int storage,
                                  hipStream_t s);
-// tiles -= K G over the work list (I,J pairs, device array) of `nwork` owned lower-triangle tiles
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int storage, int grid_cap,
+// tiles -= sum_{i < npairs} K_i G_i (in slot order) over the work list (I,J pairs, device array) of `nwork` owned
+// lower-triangle tiles: ONE pass over P for npairs update-steps
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int npairs, int storage, int grid_cap,
                            hipStream_t s);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

@@ -41,6 +41,26 @@ __device__ __forceinline__ void pmm_low_store(TS *__restrict__ tiles, const Tile
     tiles[tm.tile_offset(I, J) + ((r & m) << tm.shift) + (c & m)] = (TS)v;
 }
 
+// THE rank-2 element update.  One definition, no FP contraction left to the compiler, so that the deferred
+// path (rows patched on the fly from pending pairs) and the flush (pairs applied to the tiles) produce
+// bit-identical values, and sharded == unsharded.
+__device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
+    return fma(-k.y, g.y, fma(-k.x, g.x, v));       // v - K(r,1) G(1,c) - K(r,2) G(2,c): two FMAs, fixed order
+}
+
+// live value of canonical element (r >= c enforced here) = base - sum over pending pairs, in slot order
+template <typename TS>
+__device__ __forceinline__ double pmm_live(const TS *__restrict__ tiles, const DevState &st, int npend, int64_t r, int64_t c) {
+    if (r < c) { const int64_t t = r; r = c; c = t; }
+    double v = pmm_low<TS>(tiles, st.tm, r, c);
+    for (int i = 0; i < npend; ++i) {
+        const double2 k = reinterpret_cast<const double2 *>(st.Kp + (int64_t)i * st.pair_stride)[r];
+        const double2 g = reinterpret_cast<const double2 *>(st.Gp + (int64_t)i * st.pair_stride)[c];
+        v = rank2_apply(v, k, g);
+    }
+    return v;
+}
+
 // full-state element P(r,c), r,c in [0, 3+n_mm)
 template <typename TS>
 __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, int64_t c) {
@@ -210,8 +230,8 @@ struct PanelView {
 
 // Each shard copies the chunks of M it owns (canonical lower-triangle entries) into its send slab.
 template <typename TS>
-__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, double *__restrict__ send,
-                                                     int64_t nchunks_local) {
+__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int npend,
+                                                     double *__restrict__ send, int64_t nchunks_local) {
     const TileMap &tm = st.tm;
     const TS *__restrict__ tiles = (const TS *)st.tiles;
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // local column: kl * T + cc
@@ -221,7 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
     const int64_t kl = e >> tm.shift, cc = e & (tm.T - 1);
     const int64_t c = ((k0 + kl * tm.world) << tm.shift) + cc;
     double m0 = 0.0, m1 = 0.0;
-    if (c < n_mm) { m0 = pmm_low<TS>(tiles, tm, j, c); m1 = pmm_low<TS>(tiles, tm, j + 1, c); }
+    if (c < n_mm) { m0 = pmm_live<TS>(tiles, st, npend, j, c); m1 = pmm_live<TS>(tiles, st, npend, j + 1, c); }
     reinterpret_cast<double2 *>(send)[e] = make_double2(m0, m1);
 }
 
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
             const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
             pss[tid] = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
         } else {
-            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
+            pss[tid] = pmm_live<TS>(tiles, st, a.npend, j + t, j + b);
         }
     }
     else if (tid < 22) pss[tid] = x[tid - 19];
@@ -255,19 +275,21 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 
     const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
     const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
+    double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + (int64_t)a.npend * st.pair_stride);
+    double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + (int64_t)a.npend * st.pair_stride);
     if (c < a.n_mm) {
         // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part right)
         double m0, m1;
         if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
-        else { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
+        else { m0 = pmm_live<TS>(tiles, st, a.npend, j, c); m1 = pmm_live<TS>(tiles, st, a.npend, j + 1, c); }
         const double s0 = strip[c], s1 = strip[ldm + c], s2 = strip[2 * ldm + c];
         double g[2];
         for (int r = 0; r < 2; ++r)
             g[r] = sol.Hs[r][0] * s0 + sol.Hs[r][1] * s1 + sol.Hs[r][2] * s2 + sol.Hs[r][3] * m0 + sol.Hs[r][4] * m1;
         const double k0 = g[0] * sol.Phi[0] + g[1] * sol.Phi[2];
         const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
-        reinterpret_cast<double2 *>(st.Gi)[c] = make_double2(g[0], g[1]);
-        reinterpret_cast<double2 *>(st.Ki)[c] = make_double2(k0, k1);
+        Gout[c] = make_double2(g[0], g[1]);
+        Kout[c] = make_double2(k0, k1);
         st.x[nxt][3 + c] = x[3 + c] + (k0 * sol.nu[0] + k1 * sol.nu[1]);
         double *__restrict__ sn = st.strip[nxt];
         sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
@@ -275,8 +297,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         sn[2 * ldm + c] = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
     } else if (c < pad_end) {
         // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
-        reinterpret_cast<double2 *>(st.Gi)[c] = make_double2(0.0, 0.0);
-        reinterpret_cast<double2 *>(st.Ki)[c] = make_double2(0.0, 0.0);
+        Gout[c] = make_double2(0.0, 0.0);
+        Kout[c] = make_double2(0.0, 0.0);
     }
     if (c == 0) {
         for (int b = 0; b < 3; ++b)
@@ -302,16 +324,19 @@ template <> struct Vec2<float> { using type = float2; };
 
 template <typename TS, int T, int kSlab>
 __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, const int2 *__restrict__ work,
-                                                     int64_t nwork, const double *__restrict__ Ki,
-                                                     const double *__restrict__ Gi, TileMap tm) {
-    // kSlab = rows of a tile one workgroup pass handles (T = whole tile); a work item is (tile, slab)
+                                                     int64_t nwork, const double *__restrict__ Kp,
+                                                     const double *__restrict__ Gp, int64_t pair_stride, int npairs,
+                                                     TileMap tm) {
+    // kSlab = rows of a tile one workgroup handles (T = whole tile); a work item is (tile, slab).
+    // npairs pending (K_i, G_i) pairs are applied, in slot order, to registers between ONE load and ONE
+    // store of every element: one pass over P for npairs update-steps.
     using V2 = typename Vec2<TS>::type;
     constexpr int kPairsPerRow = T / 2;
     constexpr int kRowsPerPass = kBlock / kPairsPerRow;
     constexpr int kSlabsPerTile = T / kSlab;
     constexpr int kPasses = (kSlab + kRowsPerPass - 1) / kRowsPerPass;
-    constexpr int kUnroll = kPasses < 8 ? kPasses : 8;
     constexpr bool kExact = kRowsPerPass * kPasses == kSlab;
+    static_assert(kPasses <= 8, "slab too tall for the register tile");
     const int tid = threadIdx.x;
     const int cp = tid % kPairsPerRow;       // column pair inside the tile
     const int r0 = tid / kPairsPerRow;       // first row of this lane inside the slab
@@ -321,31 +346,97 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
         const int slab = (int)(it - w * kSlabsPerTile);
         const int2 ij = work[w];
         TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)slab * kSlab * T;
-        const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gi) + ((int64_t)ij.y * T + 2 * cp);
-        const double2 ga = g2[0], gb = g2[1];                      // (G1,G2) at columns 2cp and 2cp+1
-        const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Ki) + ((int64_t)ij.x * T + slab * kSlab);
-#pragma unroll 1
-        for (int p0 = 0; p0 < kPasses; p0 += kUnroll) {
-            V2 v[kUnroll];
-            double2 k[kUnroll];
+        double2 v[kPasses];
 #pragma unroll
-            for (int p = 0; p < kUnroll; ++p) {
-                const int r = r0 + (p0 + p) * kRowsPerPass;
+        for (int p = 0; p < kPasses; ++p) {
+            const int r = r0 + p * kRowsPerPass;
+            if (kExact || r < kSlab) {
+                const V2 t = *reinterpret_cast<const V2 *>(tp + r * T + 2 * cp);
+                v[p] = make_double2((double)t.x, (double)t.y);
+            }
+        }
+        const int64_t gcol = (int64_t)ij.y * T + 2 * cp;
+        const int64_t krow = (int64_t)ij.x * T + slab * kSlab;
+        for (int i = 0; i < npairs; ++i) {
+            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + (int64_t)i * pair_stride) + gcol;
+            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)i * pair_stride) + krow;
+            const double2 ga = g2[0], gb = g2[1];                  // (G1,G2) at columns 2cp and 2cp+1
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                const int r = r0 + p * kRowsPerPass;
                 if (kExact || r < kSlab) {
-                    v[p] = *reinterpret_cast<const V2 *>(tp + r * T + 2 * cp);
-                    k[p] = k2[r];
+                    const double2 k = k2[r];
+                    v[p].x = rank2_apply(v[p].x, k, ga);
+                    v[p].y = rank2_apply(v[p].y, k, gb);
                 }
             }
+        }
 #pragma unroll
-            for (int p = 0; p < kUnroll; ++p) {
-                const int r = r0 + (p0 + p) * kRowsPerPass;
-                if (kExact || r < kSlab) {
-                    V2 o;
-                    o.x = (TS)((double)v[p].x - (k[p].x * ga.x + k[p].y * ga.y));
-                    o.y = (TS)((double)v[p].y - (k[p].x * gb.x + k[p].y * gb.y));
-                    *reinterpret_cast<V2 *>(tp + r * T + 2 * cp) = o;
-                }
+        for (int p = 0; p < kPasses; ++p) {
+            const int r = r0 + p * kRowsPerPass;
+            if (kExact || r < kSlab) {
+                V2 o;
+                o.x = (TS)v[p].x; o.y = (TS)v[p].y;
+                *reinterpret_cast<V2 *>(tp + r * T + 2 * cp) = o;
             }
+        }
+    }
+}
+
+// Wave-row variant for T = 64 / 128 (the production tile sizes).  A wavefront owns kSlab/4 CONSECUTIVE rows
+// of the slab, so the K values it needs for one pair are one contiguous, wave-uniform run: they are fetched
+// with scalar loads (no vector-memory or LDS traffic) and feed v_fma_f64 as SGPR operands.  Per pending pair a
+// lane issues two 16-byte G loads (L1/L2 hits) and 4 FMAs per row pass; the tile data are loaded once and
+// stored once whatever the number of pairs.  With one pair and kSlab = rows of one pass this is the plain
+// streaming kernel; with m pairs and a taller slab it is one pass over P for m update-steps.
+template <typename TS, int T, int kSlab>
+__global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, const int2 *__restrict__ work,
+                                                       int64_t nwork, const double *__restrict__ Kp,
+                                                       const double *__restrict__ Gp, int64_t pair_stride, int npairs,
+                                                       TileMap tm) {
+    using V2 = typename Vec2<TS>::type;
+    constexpr int kLanesPerRow = T / 2;                   // 64 (T=128) or 32 (T=64)
+    constexpr int kRowsPerInstr = 64 / kLanesPerRow;      // rows one wave instruction covers: 1 or 2
+    constexpr int kRowsPerWave = kSlab / 4;               // consecutive rows owned by a wavefront
+    constexpr int kPasses = kRowsPerWave / kRowsPerInstr;
+    constexpr int kSlabsPerTile = T / kSlab;
+    static_assert(kPasses >= 1 && kPasses <= 8 && kPasses * kRowsPerInstr * 4 == kSlab, "bad slab");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = lane / kLanesPerRow;                  // which of the kRowsPerInstr rows this lane is on
+    const int cp = lane % kLanesPerRow;                   // column pair inside the tile
+    const int64_t nitems = nwork * kSlabsPerTile;
+    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int64_t w = it / kSlabsPerTile;
+        const int slab = (int)(it - w * kSlabsPerTile);
+        const int2 ij = work[w];
+        const int row0 = slab * kSlab + wave * kRowsPerWave;            // first tile row of this wavefront
+        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + 2 * cp;
+        double2 v[kPasses];
+#pragma unroll
+        for (int p = 0; p < kPasses; ++p) {
+            const V2 t = *reinterpret_cast<const V2 *>(tp + (int64_t)p * kRowsPerInstr * T);
+            v[p] = make_double2((double)t.x, (double)t.y);
+        }
+        const int64_t gcol = (int64_t)ij.y * T + 2 * cp;
+        const int64_t krow = (int64_t)ij.x * T + row0;                  // wave-uniform
+        for (int i = 0; i < npairs; ++i) {
+            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + (int64_t)i * pair_stride) + gcol;
+            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)i * pair_stride) + krow;
+            const double2 ga = g2[0], gb = g2[1];                       // (G1,G2) at columns 2cp and 2cp+1
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                double2 k = k2[p * kRowsPerInstr];                      // uniform address: scalar load (T = 128)
+                if (kRowsPerInstr == 2) { const double2 k1 = k2[p * 2 + 1]; if (sub) k = k1; }
+                v[p].x = rank2_apply(v[p].x, k, ga);
+                v[p].y = rank2_apply(v[p].y, k, gb);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kPasses; ++p) {
+            V2 o;
+            o.x = (TS)v[p].x; o.y = (TS)v[p].y;
+            *reinterpret_cast<V2 *>(tp + (int64_t)p * kRowsPerInstr * T) = o;
         }
     }
 }
@@ -381,7 +472,7 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
         const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
         for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b)
-            pss[15 + 2 * t + b] = have_diag ? pmm_low<TS>(tiles, st.tm, j + t, j + b) : NAN;
+            pss[15 + 2 * t + b] = have_diag ? pmm_live<TS>(tiles, st, a.npend, j + t, j + b) : NAN;
         for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
         SmallSolve sol;
@@ -601,13 +692,13 @@ int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm) {
     return k0 >= nt ? 0 : (nt - k0 + tm.world - 1) / tm.world;
 }
 
-hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, double *send, int storage, hipStream_t s) {
+hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s) {
     const int64_t nloc = rowpanel_local_chunks(st.tm, j, n_mm);
     if (nloc == 0) return hipSuccess;
     const int64_t grid = cdiv(nloc * st.tm.T, kBlock);
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, send, nloc),
-        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, send, nloc));
+        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, npend, send, nloc),
+        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, npend, send, nloc));
     return hipGetLastError();
 }
 
@@ -624,37 +715,47 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 }
 
 template <typename TS, int T, int kSlab>
-static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, hipStream_t s) {
+static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, hipStream_t s) {
     int64_t grid = nwork * (T / kSlab);
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
-                       st.Ki, st.Gi, st.tm);
+    if (T >= 64)
+        hipLaunchKernelGGL((k_downdate_w<TS, (T >= 64 ? T : 64), (T >= 64 ? kSlab : 8)>), dim3((unsigned)grid), dim3(kBlock), 0, s,
+                           (TS *)st.tiles, work, nwork, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+    else
+        hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
+                           st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
     return hipGetLastError();
 }
 
-// Default granularity: ONE pass per workgroup (each lane loads, updates and stores exactly one 16-byte column
-// pair; a workgroup covers 4 KiB of a tile).  Measured on MI355X at 10k landmarks (profiles/round1_tuning.md):
-// 1 pass 6.06 TB/s, 2 passes 5.62, 4 passes 5.58, whole 64x64 tile (8 passes) 5.49; persistent grids
-// (1024-8192 workgroups) and nontemporal loads/stores made no difference or lost 3-5 %.
-// EKF_DOWNDATE_SLAB (rows per workgroup) and EKF_DOWNDATE_GRID (grid cap) remain as tuning hooks.
+// Granularity.  One pair: ONE pass per workgroup (each lane loads, updates and stores exactly one 16-byte
+// column pair; a workgroup covers 4 KiB of a tile): 6.06 TB/s at 10k landmarks vs 5.49 TB/s for a whole
+// 64x64 tile per workgroup (profiles/round1_tuning.md).  Several pairs: the G vectors are re-read from L2
+// once per workgroup and pair, so a taller slab amortises them.  EKF_DOWNDATE_SLAB /
+// EKF_DOWNDATE_SLAB_BATCH (rows per workgroup for 1 pair / several pairs) and EKF_DOWNDATE_GRID (grid cap)
+// are tuning hooks.
 template <typename TS>
-static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int grid_cap, int slab, hipStream_t s) {
-    if (nwork <= 0) return hipSuccess;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, grid_cap, s)
+static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, int slab, hipStream_t s) {
+    if (nwork <= 0 || npairs <= 0) return hipSuccess;
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, npairs, grid_cap, s)
     switch (st.tm.T) {
         case 16: EKF_DD(16, 16);
         case 32: if (slab == 32) EKF_DD(32, 32); EKF_DD(32, 16);
-        case 64: if (slab == 64) EKF_DD(64, 64); if (slab == 32) EKF_DD(64, 32); if (slab == 16) EKF_DD(64, 16); EKF_DD(64, 8);
-        case 128: if (slab == 128) EKF_DD(128, 128); if (slab == 32) EKF_DD(128, 32); if (slab == 8) EKF_DD(128, 8); EKF_DD(128, 4);
+        case 64: if (slab == 64) EKF_DD(64, 64); if (slab == 32) EKF_DD(64, 32); if (slab == 16) EKF_DD(64, 16);
+                 if (slab == 8) EKF_DD(64, 8); if (npairs > 1) EKF_DD(64, 64); EKF_DD(64, 8);
+        case 128: if (slab == 32) EKF_DD(128, 32); if (slab == 16) EKF_DD(128, 16); if (slab == 8) EKF_DD(128, 8);
+                  if (slab == 4) EKF_DD(128, 4); if (npairs > 1) EKF_DD(128, 32); EKF_DD(128, 4);
         default: return hipErrorInvalidValue;
     }
 #undef EKF_DD
 }
 
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int storage, int grid_cap, hipStream_t s) {
-    static const int slab = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
-    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, grid_cap, slab, s)
-                        : launch_downdate_t<float>(st, work, nwork, grid_cap, slab, s);
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int npairs, int storage, int grid_cap,
+                           hipStream_t s) {
+    static const int slab1 = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
+    static const int slabm = [] { const char *v = getenv("EKF_DOWNDATE_SLAB_BATCH"); return v ? atoi(v) : 0; }();
+    const int slab = npairs > 1 ? slabm : slab1;
+    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, npairs, grid_cap, slab, s)
+                        : launch_downdate_t<float>(st, work, nwork, npairs, grid_cap, slab, s);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

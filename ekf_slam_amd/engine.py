@@ -24,7 +24,8 @@ def _colmajor(M):
 
 
 class Engine:
-    def __init__(self, mode="known", capacity=1024, tile=0, storage="f64", device=0, rank=0, world=1, **overrides):
+    def __init__(self, mode="known", capacity=1024, tile=0, storage="f64", device=0, rank=0, world=1, batch=1,
+                 **overrides):
         self.lib = L.lib()
         cfg = L.EkfConfig()
         m = L.EKF_MODE_KNOWN if mode in ("known", "EKF_SLAM") else L.EKF_MODE_UC
@@ -32,7 +33,7 @@ class Engine:
         cfg.capacity_landmarks = int(capacity)
         cfg.tile = int(tile)
         cfg.storage = L.EKF_STORE_F64 if storage == "f64" else L.EKF_STORE_F32
-        cfg.device, cfg.rank, cfg.world = int(device), int(rank), int(world)
+        cfg.device, cfg.rank, cfg.world, cfg.batch = int(device), int(rank), int(world), int(batch)
         for k, v in overrides.items():
             if k == "Rc":
                 cfg.Rc[0], cfg.Rc[1] = float(v[0]), float(v[1])
@@ -131,6 +132,14 @@ class Engine:
         if w_pos is not None: c.w_pos = float(w_pos)
         rc2 = (ctypes.c_double * 2)(c.Rc[0], c.Rc[1])
         self._check(self.lib.ekf_set_params(self.h, c.C, rc2, c.s_cost, c.s_thresh, c.w_pos))
+
+    def flush(self):
+        self._check(self.lib.ekf_flush(self.h))
+
+    def pending(self):
+        n = ctypes.c_int32()
+        self._check(self.lib.ekf_pending(self.h, ctypes.byref(n)))
+        return int(n.value)
 
     def sync(self):
         self._check(self.lib.ekf_sync(self.h))

@@ -139,5 +139,9 @@ class ShardGroup:
             P[hole] = Q[hole]
         return P
 
+    def flush(self):
+        for e in self.shards:
+            e.flush()
+
     def digest(self):
         return sum(e.digest() for e in self.shards)

@@ -63,7 +63,11 @@ typedef struct ekf_config {
     int32_t tile;                /* tile edge T in elements: 16, 32, 64 or 128; 0 = default (64)    */
     int32_t rank;                /* shard rank  (0 when world == 1)                                 */
     int32_t world;               /* number of shards P is split over; 0 or 1 = unsharded            */
-    int32_t reserved[8];
+    int32_t batch;               /* deferred downdate: up to `batch` corrections are kept as pending rank-2
+                                    pairs (the rows later corrections need are patched on the fly) and applied
+                                    to P in ONE pass; results are bit-identical to batch = 1.  0 or 1 = every
+                                    correction rewrites P immediately (EKF_SLAM.m:145 as written)       */
+    int32_t reserved[7];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;
@@ -83,6 +87,10 @@ const char *ekf_last_error(const ekf_handle *h);
  * handle's own stream. */
 int32_t     ekf_set_stream(ekf_handle *h, void *hip_stream);
 int32_t     ekf_sync(ekf_handle *h);
+/* Apply all pending rank-2 pairs to P now (no-op when nothing is pending).  Every call that reads P
+ * (ekf_get_P, ekf_get_P_block, ekf_P_digest) does this itself. */
+int32_t     ekf_flush(ekf_handle *h);
+int32_t     ekf_pending(ekf_handle *h, int32_t *npending);
 /* The reference's tunables are public properties that may be reassigned at any time (EKF_SLAM.m:12-16):
  * update C, Rc, s_cost, s_thresh, w_pos of a live handle. */
 int32_t     ekf_set_params(ekf_handle *h, double C, const double Rc[2], double s_cost, double s_thresh, double w_pos);

@@ -1,0 +1,115 @@
+"""GPU: deferred rank-2m downdate (cfg.batch > 1).  Pending (K,G) pairs are patched into the rows later
+corrections / associations read and applied to P in one pass; the results must be BIT-IDENTICAL to the
+immediate path (batch = 1), whatever is interleaved (predicts, appends, associations, sharding), and within
+1e-6 of the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _state(N, seed):
+    rng = np.random.default_rng(seed)
+    n = 3 + 2 * N
+    x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N)])
+    U = rng.normal(0, 0.05, size=(n, 6))
+    return x, np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T, np.arange(1, N + 1.0)
+
+
+@pytest.mark.parametrize("batch,tile", [(2, 16), (5, 16), (8, 64), (16, 32), (64, 64)])
+def test_deferred_equals_immediate_bitwise(batch, tile, oracle_lib):
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 140
+    x, P, s = _state(N, 41)
+    imm = Engine(capacity=N + 30, tile=tile, batch=1)
+    dfr = Engine(capacity=N + 30, tile=tile, batch=batch)
+    ref = StructuredEKF(N + 30, "known")
+    for e in (imm, dfr, ref):
+        e.set_state(x, P, s)
+    rng = np.random.default_rng(8)
+    for step in range(37):
+        u = [0.1, 3.0]
+        for e in (imm, dfr, ref):
+            e.predict(u)
+        for _ in range(int(rng.integers(1, 4))):
+            idx0 = int(rng.integers(0, imm.N))
+            z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+            R = np.diag([z[0] * .01, z[1] * 5.0])
+            imm.correct(z, R, idx0); dfr.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+        if step % 5 == 2:                  # grow the map while pairs are pending
+            pos, sig = rng.uniform(-5, 5, 2), imm.N + 1
+            R = np.diag([0.2, 40.0])
+            for e in (imm, dfr, ref):
+                e.append(u, R, pos, sig)
+            z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+            imm.correct(z, R, imm.N - 1); dfr.correct(z, R, dfr.N - 1); ref.correct(z, R, ref.N)
+        np.testing.assert_array_equal(dfr.get_x(), imm.get_x())      # x is always current, no flush involved
+    assert batch == 2 or dfr.pending() > 0 or batch > 37
+    Pd, Pi = dfr.get_P(), imm.get_P()                                 # get_P flushes
+    assert dfr.pending() == 0
+    np.testing.assert_array_equal(Pd, Pi)
+    assert rel_err(Pd, ref.P) < REL and rel_err(dfr.get_x(), ref.x) < REL
+    np.testing.assert_allclose(dfr.digest(), imm.digest(), rtol=1e-13)
+
+
+def test_deferred_uc_slam_run_matches_golden():
+    from golden_util import load, rel_err as rerr, replay_slam
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    g = load("slam120_uc_nearest.npz")
+    e = EKF_SLAM_UC(capacity=128, tile=32, batch=16, Rc=list(g["Rc"]))
+    poses = replay_slam(e, Landmark('SYNTHETIC'), g)
+    assert rerr(poses, g["poses"]) < REL and rerr(e.x, g["x"]) < REL and rerr(e.P, g["P"]) < REL
+
+
+def test_deferred_association_costs_see_pending_pairs(oracle_lib):
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 300
+    x, P, s = _state(N, 43)
+    e = Engine(mode="uc", capacity=N, tile=64, batch=8)
+    ref = StructuredEKF(N, "uc")
+    e.set_state(x, P, s); ref.set_state(x, P, s)
+    rng = np.random.default_rng(2)
+    for idx0 in (0, 150, 299, 31, 32):
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .1, z[1] * 5.0])
+        e.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+    assert e.pending() == 5
+    R = np.diag([1.0, 50.0])
+    new_g, idx_g, pc_g, sc_g = e.associate([7.0, 123.0, 151.0], R, want_costs=True)
+    new_r, idx_r, pc_r, sc_r = ref.associate([7.0, 123.0, 151.0], R, want_costs=True)
+    assert (new_g, idx_g + 1) == (new_r, idx_r) == (False, 151)
+    assert rel_err(pc_g, pc_r) < REL
+    assert e.pending() == 5
+
+
+@pytest.mark.parametrize("world,batch", [(2, 4), (3, 7), (4, 16)])
+def test_deferred_sharded_bitwise(world, batch):
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 120
+    x, P, s = _state(N, 47)
+    g = ShardGroup(world, capacity=N + 8, tile=16, batch=batch)
+    one = Engine(capacity=N + 8, tile=16, batch=1)
+    g.set_state(x, P, s); one.set_state(x, P, s)
+    rng = np.random.default_rng(6)
+    for step in range(23):
+        u = [0.1, 3.0]
+        g.predict(u); one.predict(u)
+        idx0 = int(rng.integers(0, one.N))
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        g.correct(z, R, idx0); one.correct(z, R, idx0)
+        if step == 11:
+            pos = rng.uniform(-5, 5, 2)
+            g.append(u, R, pos, one.N + 1); one.append(u, R, pos, one.N + 1)
+    np.testing.assert_array_equal(g.get_x(), one.get_x())
+    np.testing.assert_array_equal(g.get_P(), one.get_P())
+    g.close()
