@@ -68,12 +68,21 @@ def attach_communicator(engine, dist, torch, prefer="rccl"):
     engine.set_stream(torch.cuda.current_stream().cuda_stream)
     engine._xchg_tensors = (send, recv)
 
+    staged = dist.get_backend() != "nccl"      # e.g. gloo (rehearsals on one GPU): stage through host memory
+
     def host_exchange(e):
         _, _, cnt, _ = e.exchange_info()
-        dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
+        if staged:
+            torch.cuda.current_stream().synchronize()
+            s_cpu = send[:cnt].cpu()
+            parts = [torch.empty_like(s_cpu) for _ in range(world)]
+            dist.all_gather(parts, s_cpu)
+            recv[:cnt * world].copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
 
     engine._host_exchange = host_exchange
-    return "torch.distributed"
+    return "torch.distributed" if not staged else "torch.distributed(%s, host-staged)" % dist.get_backend()
 
 
 class ShardGroup:
