@@ -66,6 +66,10 @@ struct ekf_handle {
     int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
     int32_t batch = 1;     // max pending rank-2 pairs
     int32_t npend = 0;     // pending pairs (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
+    // lazy predict: ekf_predict only records u; the next correction folds it into its gather kernel (one launch
+    // instead of two, identical arithmetic); any other consumer of x / P launches k_predict first
+    bool have_pp = false;
+    PredictArgs pp;
     DevState st;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // work list of owned lower-triangle tiles for the active tile rows
@@ -184,9 +188,11 @@ int32_t flush_pending(ekf_handle *h) {
     return EKF_OK;
 }
 
-int32_t do_predict(ekf_handle *h, const double u[2]) {
-    PredictArgs a;
-    a.u0 = u[0]; a.u1 = u[1]; a.C = h->cfg.C; a.n_mm = n_mm(h); a.cur = h->cur;
+int32_t materialize_predict(ekf_handle *h) {
+    if (!h->have_pp) return EKF_OK;
+    h->have_pp = false;
+    PredictArgs a = h->pp;
+    a.n_mm = n_mm(h); a.cur = h->cur;
     {
         TimedLaunch tl(h, EKF_KERNEL_PREDICT);
         HIPCHK(h, launch_predict(h->st, a, h->storage, h->stream));
@@ -195,8 +201,27 @@ int32_t do_predict(ekf_handle *h, const double u[2]) {
     return EKF_OK;
 }
 
+int32_t do_predict(ekf_handle *h, const double u[2]) {
+    int32_t rc = materialize_predict(h);           // an earlier predict that nothing consumed yet
+    if (rc) return rc;
+    h->pp.u0 = u[0]; h->pp.u1 = u[1]; h->pp.C = h->cfg.C; h->pp.n_mm = 0; h->pp.cur = 0;
+    h->have_pp = true;
+    static const bool lazy = [] { const char *v = getenv("EKF_LAZY_PREDICT"); return !v || atoi(v) != 0; }();
+    return lazy ? EKF_OK : materialize_predict(h);
+}
+
+// device + every deferred host-side decision that the caller's next read depends on
+int32_t enter(ekf_handle *h) {
+    HIPCHK(h, hipSetDevice(h->cfg.device));
+    return materialize_predict(h);
+}
+
 int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature) {
     REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
+    {
+        const int32_t rcp = materialize_predict(h);
+        if (rcp) return rcp;
+    }
     AppendArgs a;
     a.u0 = u[0]; a.u1 = u[1];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
@@ -235,7 +260,9 @@ int32_t correct_finish(ekf_handle *h) {
     h->pending = false;
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
-        HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, h->recv, h->slab, h->storage, h->stream));
+        const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+        HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, fuse, h->recv, h->slab, h->storage, h->stream));
+        h->have_pp = false;
     }
     h->cur ^= 1;
     h->npend += 1;
@@ -268,7 +295,9 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
-        HIPCHK(h, launch_gather(h->st, a, h->storage, h->stream));
+        const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+        HIPCHK(h, launch_gather(h->st, a, fuse, h->storage, h->stream));
+        h->have_pp = false;
     }
     h->cur ^= 1;
     h->npend += 1;
@@ -280,6 +309,10 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
     REQUIRE(h, h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
             "associate: w_pos != 0 needs the diagonal blocks of other shards (not supported on a sharded handle)");
+    {
+        const int32_t rcp = materialize_predict(h);
+        if (rcp) return rcp;
+    }
     AssocArgs a;
     a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
@@ -369,7 +402,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->capacity_landmarks < 1 || cfg->rank < 0 || cfg->rank >= world) return EKF_ERR_INVALID_ARG;
     if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
     if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;
-    if (cfg->batch < 0 || cfg->batch > 1024) return EKF_ERR_INVALID_ARG;
+    if (cfg->batch < 0 || cfg->batch > 64) return EKF_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return EKF_ERR_NO_DEVICE;
@@ -460,7 +493,7 @@ const char *ekf_last_error(const ekf_handle *h) { return h ? h->err.c_str() : "n
 
 int32_t ekf_set_stream(ekf_handle *h, void *hip_stream) {
     if (!h) return EKF_ERR_INVALID_ARG;
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
@@ -469,7 +502,7 @@ int32_t ekf_set_stream(ekf_handle *h, void *hip_stream) {
 
 int32_t ekf_sync(ekf_handle *h) {
     if (!h) return EKF_ERR_INVALID_ARG;
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return EKF_OK;
@@ -678,7 +711,7 @@ int32_t ekf_num_landmarks(ekf_handle *h, int64_t *N) {
 
 int32_t ekf_get_x(ekf_handle *h, double *x) {
     if (!h || !x) return fail(h, EKF_ERR_INVALID_ARG, "get_x: null argument");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(x, h->st.x[h->cur], (size_t)(3 + n_mm(h)) * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -688,7 +721,7 @@ int32_t ekf_get_x(ekf_handle *h, double *x) {
 int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     if (!h || !x) return fail(h, EKF_ERR_INVALID_ARG, "set_x: null argument");
     REQUIRE(h, n >= 3 && (n - 3) % 2 == 0 && (n - 3) / 2 <= h->cap, EKF_ERR_INVALID_ARG, "set_x: bad length");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     rc = flush_pending(h);     // pending pairs belong to the old state
     if (rc) return rc;
@@ -704,7 +737,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
 
 int32_t ekf_get_s(ekf_handle *h, double *s) {
     if (!h || (!s && h->N > 0)) return fail(h, EKF_ERR_INVALID_ARG, "get_s: null argument");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     if (h->N > 0) HIPCHK(h, hipMemcpyAsync(s, h->st.s, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -714,7 +747,7 @@ int32_t ekf_get_s(ekf_handle *h, double *s) {
 int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
     if (!h || (!s && N > 0)) return fail(h, EKF_ERR_INVALID_ARG, "set_s: null argument");
     REQUIRE(h, N == h->N, EKF_ERR_INVALID_ARG, "set_s: length must equal the number of landmarks (set x first)");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     if (N > 0) HIPCHK(h, hipMemcpyAsync(h->st.s, s, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -723,7 +756,7 @@ int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
 
 int32_t ekf_get_P(ekf_handle *h, double *P) {
     if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "get_P: null argument");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     rc = flush_pending(h);
     if (rc) return rc;
@@ -741,7 +774,7 @@ int32_t ekf_get_P(ekf_handle *h, double *P) {
 int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
     if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "set_P: null argument");
     REQUIRE(h, n == 3 + n_mm(h), EKF_ERR_INVALID_ARG, "set_P: n must equal length(x) (set x first)");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     h->npend = 0;              // the whole covariance is replaced
     double *dense = nullptr;
@@ -759,7 +792,7 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
     const int64_t n = 3 + n_mm(h);
     REQUIRE(h, r0 >= 0 && c0 >= 0 && nr >= 1 && nc >= 1 && r0 + nr <= n && c0 + nc <= n, EKF_ERR_INVALID_ARG,
             "get_P_block: block outside P");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     rc = flush_pending(h);
     if (rc) return rc;
@@ -775,7 +808,7 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
 
 int32_t ekf_get_Q(ekf_handle *h, double Q[9]) {
     if (!h || !Q) return fail(h, EKF_ERR_INVALID_ARG, "get_Q: null argument");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->h_small, h->st.small, 32 * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -787,7 +820,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
                                const double *U, int64_t k) {
     if (!h || !x || !s || !d || !U) return fail(h, EKF_ERR_INVALID_ARG, "load_lowrank_state: null argument");
     REQUIRE(h, N >= 0 && N <= h->cap && k >= 1, EKF_ERR_INVALID_ARG, "load_lowrank_state: bad N or k");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     const int64_t n = 3 + 2 * N;
     if (N < h->N) {
@@ -815,7 +848,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
 
 int32_t ekf_P_digest(ekf_handle *h, double out[3]) {
     if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "P_digest: null argument");
-    int32_t rc = use_device(h);
+    int32_t rc = enter(h);
     if (rc) return rc;
     rc = flush_pending(h);
     if (rc) return rc;

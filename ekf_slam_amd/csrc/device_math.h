@@ -16,21 +16,23 @@ namespace ekfm {
 constexpr double kD2R = 0.017453292519943295;
 constexpr double kR2D = 57.29577951308232;
 
-// a (deg, |a| < 360) = 90*n + r with r in [-45,45]; quad = n mod 4.  round() is half-away-from-zero.
+// a (deg) = 90*n + r with r in [-45,45]; quad = n mod 4.  round() is half-away-from-zero.
+// No fmod: for |a| < 2^40 the quotient of an exact multiple of 90 is exact, 90*n is exactly representable and
+// a - 90*n is exact (Sterbenz), so r (and exactness at multiples of 90 degrees) is the same as reducing
+// mod 360 first -- and f64 fmod is by far the slowest thing in these kernels' scalar prologues.
 EKF_MHD void reduce90(double a, double &r, int &quad) {
+    if (fabs(a) >= 1099511627776.0) a = fmod(a, 360.0);
     const double q = a / 90.0;
     const double n = copysign(floor(fabs(q) + 0.5), q);
-    r = a - n * 90.0;
-    double m = fmod(n, 4.0);
-    if (m < 0.0) m += 4.0;
-    quad = (int)m;
+    r = fma(-90.0, n, a);
+    quad = (int)(((long long)n) & 3);
 }
 
 // exact at multiples of 90 degrees
 EKF_MHD double sind(double a) {
     if (!isfinite(a)) return NAN;
     double r; int quad;
-    reduce90(fmod(a, 360.0), r, quad);
+    reduce90(a, r, quad);
     const double t = kD2R * r;
     return quad == 0 ? sin(t) : quad == 1 ? cos(t) : quad == 2 ? -sin(t) : -cos(t);
 }
@@ -38,9 +40,20 @@ EKF_MHD double sind(double a) {
 EKF_MHD double cosd(double a) {
     if (!isfinite(a)) return NAN;
     double r; int quad;
-    reduce90(fmod(a, 360.0), r, quad);
+    reduce90(a, r, quad);
     const double t = kD2R * r;
     return quad == 0 ? cos(t) : quad == 1 ? -sin(t) : quad == 2 ? -cos(t) : sin(t);
+}
+
+// sind and cosd of the same angle with one reduction and one sin/cos pair
+EKF_MHD void sincosd(double a, double &sn, double &cs) {
+    if (!isfinite(a)) { sn = NAN; cs = NAN; return; }
+    double r; int quad;
+    reduce90(a, r, quad);
+    const double t = kD2R * r;
+    const double s0 = sin(t), c0 = cos(t);
+    sn = quad == 0 ? s0 : quad == 1 ? c0 : quad == 2 ? -s0 : -c0;
+    cs = quad == 0 ? c0 : quad == 1 ? -s0 : quad == 2 ? -c0 : s0;
 }
 
 EKF_MHD double atan2d(double y, double x) { return atan2(y, x) * kR2D; }
@@ -48,7 +61,11 @@ EKF_MHD double atan2d(double y, double x) { return atan2(y, x) * kR2D; }
 // mod(a,360) with positive multiples of 360 mapped to 360 (Mapping Toolbox wrapTo360)
 EKF_MHD double wrapTo360(double a) {
     if (!isfinite(a)) return NAN;
-    double w = fmod(a, 360.0);
+    // fast exact path for the usual range (one or two turns), fmod otherwise
+    double w;
+    if (a >= 0.0 && a < 720.0) w = a < 360.0 ? a : a - 360.0;     // exact
+    else if (a < 0.0 && a >= -360.0) w = a;                       // == fmod(a,360) for |a| < 360
+    else w = fmod(a, 360.0);
     if (w < 0.0) w += 360.0;
     if (w == 0.0 && a > 0.0) w = 360.0;
     return w;

@@ -68,14 +68,16 @@ constexpr int kAssocBlock = 256;
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
 hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s);
-hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, hipStream_t s);
+// fused_predict != nullptr folds predict(u) into the correction (one launch instead of two, identical arithmetic)
+hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
+                         hipStream_t s);
 // sharded correction: (1) every shard copies the chunks of the landmark row-panel P(j:j+1,:) it owns into `send`
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
 int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s);
-hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const double *recv, int64_t slab, int storage,
-                                 hipStream_t s);
+hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
+                                 int64_t slab, int storage, hipStream_t s);
 // tiles -= sum_{i < npairs} K_i G_i (in slot order) over the work list (I,J pairs, device array) of `nwork` owned
 // lower-triangle tiles: ONE pass over P for npairs update-steps
 hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int npairs, int storage, int grid_cap,

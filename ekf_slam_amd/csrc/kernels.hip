@@ -76,37 +76,65 @@ __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, i
 // ---------------------------------------------------------------------------------------------------
 // predict: one thread per strip column; thread 0 also owns the pose, Prr and Q
 // ---------------------------------------------------------------------------------------------------
+// The pose / robot-block part of predict, shared by k_predict and the predict-fused gather so that both give
+// bit-identical results.  in: pose[3], M = Prr (row-major); out: fa = F(1,3), fb = F(2,3), new pose, Prr' , Q.
+struct PredictSmall { double fa, fb; double pose[3]; double prr[9]; double Q[9]; };
+
+__device__ inline void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
+                                     PredictSmall &o) {
+    const double th = pose[2];
+    // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
+    double sn, cs, sn2, cs2;
+    ekfm::sincosd(th, sn, cs);
+    ekfm::sincosd(th + u1, sn2, cs2);
+    o.fa = -1 * u0 * sn;
+    o.fb = u0 * cs;
+    const double W[3] = { u0 * cs, u0 * sn, u1 };                                     // EKF_SLAM.m:42
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o.Q[3 * i + j] = (W[i] * C) * W[j];              // EKF_SLAM.m:44
+    double M[9];
+    for (int i = 0; i < 9; ++i) M[i] = prr_in[i];
+    for (int j = 0; j < 3; ++j) { const double p2 = M[6 + j]; M[j] += o.fa * p2; M[3 + j] += o.fb * p2; }          // F*P
+    for (int i = 0; i < 3; ++i) { const double p2 = M[3 * i + 2]; M[3 * i] += o.fa * p2; M[3 * i + 1] += o.fb * p2; }  // *F'
+    for (int i = 0; i < 9; ++i) o.prr[i] = M[i] + o.Q[i];
+    o.pose[0] = pose[0] + u0 * cs2;                                                   // EKF_SLAM.m:58-60
+    o.pose[1] = pose[1] + u0 * sn2;
+    o.pose[2] = ekfm::wrapTo360(th + u1);                                             // EKF_SLAM.m:50
+}
+
+// strip column under F*P: (F*P)(1,:) = P(1,:) + F(1,3) P(3,:), (F*P)(2,:) = P(2,:) + F(2,3) P(3,:)
+__device__ __forceinline__ void predict_strip(double &s0, double &s1, double s2, double fa, double fb) {
+    s0 = fma(fa, s2, s0);
+    s1 = fma(fb, s2, s1);
+}
+
 __global__ __launch_bounds__(kBlock) void k_predict(DevState st, PredictArgs a) {
+    __shared__ PredictSmall ps;
     const int cur = a.cur, nxt = cur ^ 1;
     const double *__restrict__ x = st.x[cur];
     double *__restrict__ xn = st.x[nxt];
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const double th = x[2];
-    // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
-    const double fa = -1 * a.u0 * ekfm::sind(th);
-    const double fb = a.u0 * ekfm::cosd(th);
+    if (threadIdx.x == 0) {
+        const double pose[3] = { x[0], x[1], x[2] };
+        double prr[9];
+        for (int i = 0; i < 9; ++i) prr[i] = st.prr[cur][i];
+        predict_small(pose, prr, a.u0, a.u1, a.C, ps);
+    }
+    __syncthreads();
     if (c < a.n_mm) {
         const double *__restrict__ s = st.strip[cur];
         double *__restrict__ sn = st.strip[nxt];
-        const double s0 = s[c], s1 = s[st.ldm + c], s2 = s[2 * st.ldm + c];
-        sn[c] = s0 + fa * s2;              // (F*P)(1,:) = P(1,:) + F(1,3) P(3,:)
-        sn[st.ldm + c] = s1 + fb * s2;
+        double s0 = s[c], s1 = s[st.ldm + c];
+        const double s2 = s[2 * st.ldm + c];
+        predict_strip(s0, s1, s2, ps.fa, ps.fb);
+        sn[c] = s0;
+        sn[st.ldm + c] = s1;
         sn[2 * st.ldm + c] = s2;
         xn[3 + c] = x[3 + c];
     }
     if (c == 0) {
-        const double W[3] = { a.u0 * ekfm::cosd(th), a.u0 * ekfm::sind(th), a.u1 };   // EKF_SLAM.m:42
-        double Q[9];
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) Q[3 * i + j] = (W[i] * a.C) * W[j];           // EKF_SLAM.m:44
-        double M[9];
-        for (int i = 0; i < 9; ++i) M[i] = st.prr[cur][i];
-        for (int j = 0; j < 3; ++j) { const double p2 = M[6 + j]; M[j] += fa * p2; M[3 + j] += fb * p2; }      // F*P
-        for (int i = 0; i < 3; ++i) { const double p2 = M[3 * i + 2]; M[3 * i] += fa * p2; M[3 * i + 1] += fb * p2; }  // *F'
-        for (int i = 0; i < 9; ++i) { st.prr[nxt][i] = M[i] + Q[i]; st.small[12 + i] = Q[i]; }
-        xn[0] = x[0] + a.u0 * ekfm::cosd(th + a.u1);                                   // EKF_SLAM.m:58-60
-        xn[1] = x[1] + a.u0 * ekfm::sind(th + a.u1);
-        xn[2] = ekfm::wrapTo360(th + a.u1);                                            // EKF_SLAM.m:50
+        for (int i = 0; i < 9; ++i) { st.prr[nxt][i] = ps.prr[i]; st.small[12 + i] = ps.Q[i]; }
+        for (int i = 0; i < 3; ++i) xn[i] = ps.pose[i];
     }
 }
 
@@ -245,16 +273,21 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
     reinterpret_cast<double2 *>(send)[e] = make_double2(m0, m1);
 }
 
-template <typename TS, bool kSharded>
-__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv) {
+constexpr int kMaxPending = 64;        // cfg.batch upper bound (LDS staging of the wave-uniform patch operands)
+
+template <typename TS, bool kSharded, bool kPredict>
+__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
+    __shared__ PredictSmall ps;
+    __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const int tid = threadIdx.x;
     const int cur = a.cur, nxt = cur ^ 1;
     const double *__restrict__ x = st.x[cur];
     const double *__restrict__ strip = st.strip[cur];
     const TS *__restrict__ tiles = (const TS *)st.tiles;
     const int64_t j = a.j, ldm = st.ldm;
+    const int npend = a.npend;
 
     if (tid < 9) pss[tid] = st.prr[cur][tid];
     else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
@@ -264,25 +297,106 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
             const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
             pss[tid] = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
         } else {
-            pss[tid] = pmm_live<TS>(tiles, st, a.npend, j + t, j + b);
+            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);    // base value; pending pairs applied below from LDS
         }
     }
     else if (tid < 22) pss[tid] = x[tid - 19];
     else if (tid < 24) pss[tid] = x[3 + j + (tid - 22)];
+    if (!kSharded) {
+        for (int e = tid; e < 4 * npend; e += kBlock) {
+            const int i = e >> 2, which = e & 3;
+            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)i * st.pair_stride;
+            upatch[e] = reinterpret_cast<const double2 *>(base)[j + (which & 1)];
+        }
+    }
     __syncthreads();
-    if (tid == 0) solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
+    if (tid == 0) {
+        if (!kSharded) {
+            // live 2x2 diagonal block: canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
+            double d00 = pss[15], d10 = pss[17], d11 = pss[18];
+            for (int i = 0; i < npend; ++i) {
+                d00 = rank2_apply(d00, upatch[4 * i + 0], upatch[4 * i + 2]);
+                d10 = rank2_apply(d10, upatch[4 * i + 1], upatch[4 * i + 2]);
+                d11 = rank2_apply(d11, upatch[4 * i + 1], upatch[4 * i + 3]);
+            }
+            pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
+        }
+        if (kPredict) {
+            // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
+            const double pose[3] = { pss[19], pss[20], pss[21] };
+            predict_small(pose, pss, pa.u0, pa.u1, pa.C, ps);
+            for (int i = 0; i < 9; ++i) pss[i] = ps.prr[i];
+            for (int b = 0; b < 2; ++b) predict_strip(pss[9 + b], pss[11 + b], pss[13 + b], ps.fa, ps.fb);
+            for (int i = 0; i < 3; ++i) pss[19 + i] = ps.pose[i];
+        }
+        solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
+    }
     __syncthreads();
 
     const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
     const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
-    double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + (int64_t)a.npend * st.pair_stride);
-    double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + (int64_t)a.npend * st.pair_stride);
+    double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + (int64_t)npend * st.pair_stride);
+    double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + (int64_t)npend * st.pair_stride);
     if (c < a.n_mm) {
-        // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part right)
+        // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part
+        // right of j+1), each patched with the pending pairs in slot order
         double m0, m1;
-        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
-        else { m0 = pmm_live<TS>(tiles, st, a.npend, j, c); m1 = pmm_live<TS>(tiles, st, a.npend, j + 1, c); }
-        const double s0 = strip[c], s1 = strip[ldm + c], s2 = strip[2 * ldm + c];
+        if (kSharded) {
+            const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y;
+        } else if (c <= j) {
+            m0 = pmm_low<TS>(tiles, st.tm, j, c);
+            m1 = pmm_low<TS>(tiles, st.tm, j + 1, c);
+            // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
+            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
+            const int64_t ps2 = st.pair_stride / 2;
+            int i = 0;
+            for (; i + 8 <= npend; i += 8) {
+                double2 g[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)(i + q) * ps2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    m0 = rank2_apply(m0, upatch[4 * (i + q) + 0], g[q]);
+                    m1 = rank2_apply(m1, upatch[4 * (i + q) + 1], g[q]);
+                }
+            }
+            for (; i < npend; ++i) {
+                const double2 g = gp[(int64_t)i * ps2];
+                m0 = rank2_apply(m0, upatch[4 * i + 0], g);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], g);
+            }
+        } else if (c >= j + 2) {
+            m0 = pmm_low<TS>(tiles, st.tm, c, j);
+            m1 = pmm_low<TS>(tiles, st.tm, c, j + 1);
+            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
+            const int64_t ps2 = st.pair_stride / 2;
+            int i = 0;
+            for (; i + 8 <= npend; i += 8) {
+                double2 k[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)(i + q) * ps2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    m0 = rank2_apply(m0, k[q], upatch[4 * (i + q) + 2]);
+                    m1 = rank2_apply(m1, k[q], upatch[4 * (i + q) + 3]);
+                }
+            }
+            for (; i < npend; ++i) {
+                const double2 k = kp[(int64_t)i * ps2];
+                m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
+            }
+        } else {                                                   // c == j + 1: canonical (j+1,j) and (j+1,j+1)
+            m0 = pmm_low<TS>(tiles, st.tm, j + 1, j);
+            m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1);
+            for (int i = 0; i < npend; ++i) {
+                m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+            }
+        }
+        double s0 = strip[c], s1 = strip[ldm + c];
+        const double s2 = strip[2 * ldm + c];
+        if (kPredict) predict_strip(s0, s1, s2, ps.fa, ps.fb);
         double g[2];
         for (int r = 0; r < 2; ++r)
             g[r] = sol.Hs[r][0] * s0 + sol.Hs[r][1] * s1 + sol.Hs[r][2] * s2 + sol.Hs[r][3] * m0 + sol.Hs[r][4] * m1;
@@ -302,11 +416,12 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     }
     if (c == 0) {
         for (int b = 0; b < 3; ++b)
-            st.x[nxt][b] = x[b] + (sol.Kr[b][0] * sol.nu[0] + sol.Kr[b][1] * sol.nu[1]);   // x(3) NOT re-wrapped
+            st.x[nxt][b] = pss[19 + b] + (sol.Kr[b][0] * sol.nu[0] + sol.Kr[b][1] * sol.nu[1]);   // x(3) NOT re-wrapped
         for (int r = 0; r < 3; ++r) for (int b = 0; b < 3; ++b)
-            st.prr[nxt][3 * r + b] = st.prr[cur][3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
+            st.prr[nxt][3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
         for (int r = 0; r < 2; ++r) for (int b = 0; b < 3; ++b) st.small[3 * r + b] = sol.Gr[r][b];
         for (int b = 0; b < 3; ++b) for (int r = 0; r < 2; ++r) st.small[6 + 2 * b + r] = sol.Kr[b][r];
+        if (kPredict) for (int i = 0; i < 9; ++i) st.small[12 + i] = ps.Q[i];
     }
 }
 
@@ -674,14 +789,18 @@ hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, h
     return hipGetLastError();
 }
 
-hipError_t launch_gather(const DevState &st, const CorrectArgs &a, int storage, hipStream_t s) {
+hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
+                         hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kBlock);
     PanelView pv;
     pv.recv = nullptr; pv.slab = 0; pv.Ij = 0;
-    EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL((k_gather<double, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv),
-        hipLaunchKernelGGL((k_gather<float, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv));
+    PredictArgs pa = {};
+    if (fused_predict) pa = *fused_predict;
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)
+    if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
+    else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
+#undef EKF_G
     return hipGetLastError();
 }
 
@@ -702,15 +821,18 @@ hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npen
     return hipGetLastError();
 }
 
-hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const double *recv, int64_t slab, int storage,
-                                 hipStream_t s) {
+hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
+                                 int64_t slab, int storage, hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kBlock);
     PanelView pv;
     pv.recv = recv; pv.slab = slab; pv.Ij = a.j >> st.tm.shift;
-    EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL((k_gather<double, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv),
-        hipLaunchKernelGGL((k_gather<float, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv));
+    PredictArgs pa = {};
+    if (fused_predict) pa = *fused_predict;
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)
+    if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
+    else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
+#undef EKF_G
     return hipGetLastError();
 }
 

@@ -66,7 +66,7 @@ typedef struct ekf_config {
     int32_t batch;               /* deferred downdate: up to `batch` corrections are kept as pending rank-2
                                     pairs (the rows later corrections need are patched on the fly) and applied
                                     to P in ONE pass; results are bit-identical to batch = 1.  0 or 1 = every
-                                    correction rewrites P immediately (EKF_SLAM.m:145 as written)       */
+                                    correction rewrites P immediately (EKF_SLAM.m:145 as written); max 64  */
     int32_t reserved[7];
 } ekf_config;
 

@@ -113,3 +113,32 @@ def test_deferred_sharded_bitwise(world, batch):
     np.testing.assert_array_equal(g.get_x(), one.get_x())
     np.testing.assert_array_equal(g.get_P(), one.get_P())
     g.close()
+
+
+def test_fused_predict_equals_standalone_predict_bitwise(oracle_lib):
+    """ekf_predict is lazy: the next correction folds it into its gather kernel.  Forcing the standalone k_predict
+    (any read of x materialises it) must not change a single bit."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 130
+    x, P, s = _state(N, 53)
+    fused = Engine(capacity=N, tile=64, batch=4)
+    split = Engine(capacity=N, tile=64, batch=4)
+    ref = StructuredEKF(N, "known")
+    for e in (fused, split, ref):
+        e.set_state(x, P, s)
+    rng = np.random.default_rng(12)
+    for step in range(11):
+        u = [0.1 + 0.01 * step, 3.0 - step]
+        fused.predict(u); split.predict(u); ref.predict(u)
+        split.get_x()                                   # materialises the predict on its own
+        if step == 5:
+            fused.predict(u); split.predict(u); ref.predict(u)      # two predicts in a row
+        idx0 = int(rng.integers(0, N))
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        fused.correct(z, R, idx0); split.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+    np.testing.assert_array_equal(fused.get_Q3(), split.get_Q3())
+    np.testing.assert_array_equal(fused.get_x(), split.get_x())
+    np.testing.assert_array_equal(fused.get_P(), split.get_P())
+    assert rel_err(fused.get_P(), ref.P) < REL and rel_err(fused.get_x(), ref.x) < REL
