@@ -396,9 +396,9 @@ int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
 int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (!cfg || !out) return EKF_ERR_INVALID_ARG;
     *out = nullptr;
-    const int32_t T = cfg->tile == 0 ? 128 : cfg->tile;
+    const int32_t T = cfg->tile == 0 ? (cfg->storage == EKF_STORE_F32 ? 256 : 128) : cfg->tile;
     const int32_t world = cfg->world <= 0 ? 1 : cfg->world;
-    if (!(T == 16 || T == 32 || T == 64 || T == 128)) return EKF_ERR_INVALID_ARG;
+    if (!(T == 16 || T == 32 || T == 64 || T == 128 || (T == 256 && cfg->storage == EKF_STORE_F32))) return EKF_ERR_INVALID_ARG;
     if (cfg->capacity_landmarks < 1 || cfg->rank < 0 || cfg->rank >= world) return EKF_ERR_INVALID_ARG;
     if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
     if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;

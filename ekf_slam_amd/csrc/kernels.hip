@@ -504,57 +504,72 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
 // lane issues two 16-byte G loads (L1/L2 hits) and 4 FMAs per row pass; the tile data are loaded once and
 // stored once whatever the number of pairs.  With one pair and kSlab = rows of one pass this is the plain
 // streaming kernel; with m pairs and a taller slab it is one pass over P for m update-steps.
+template <typename TS> struct Lane16;                       // 16 bytes of one tile row per lane
+template <> struct Lane16<double> { using type = double2; static constexpr int kCols = 2; };
+template <> struct Lane16<float>  { using type = float4;  static constexpr int kCols = 4; };
+__device__ __forceinline__ void lane16_unpack(const double2 &t, double *v) { v[0] = t.x; v[1] = t.y; }
+__device__ __forceinline__ void lane16_unpack(const float4 &t, double *v) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void lane16_pack(const double *v, double2 &t) { t.x = v[0]; t.y = v[1]; }
+__device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
+    t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
+}
+
 template <typename TS, int T, int kSlab>
 __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, const int2 *__restrict__ work,
                                                        int64_t nwork, const double *__restrict__ Kp,
                                                        const double *__restrict__ Gp, int64_t pair_stride, int npairs,
                                                        TileMap tm) {
-    using V2 = typename Vec2<TS>::type;
-    constexpr int kLanesPerRow = T / 2;                   // 64 (T=128) or 32 (T=64)
-    constexpr int kRowsPerInstr = 64 / kLanesPerRow;      // rows one wave instruction covers: 1 or 2
+    using VL = typename Lane16<TS>::type;
+    constexpr int kCols = Lane16<TS>::kCols;              // columns per lane: 2 (f64 tiles) or 4 (f32 tiles)
+    constexpr int kLanesPerRow = T / kCols;               // 64: one row per wave instruction; 32: two rows
+    constexpr int kRowsPerInstr = 64 / kLanesPerRow;
     constexpr int kRowsPerWave = kSlab / 4;               // consecutive rows owned by a wavefront
     constexpr int kPasses = kRowsPerWave / kRowsPerInstr;
     constexpr int kSlabsPerTile = T / kSlab;
+    static_assert(kLanesPerRow == 64 || kLanesPerRow == 32, "tile edge / storage type combination not supported");
     static_assert(kPasses >= 1 && kPasses <= 8 && kPasses * kRowsPerInstr * 4 == kSlab, "bad slab");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / kLanesPerRow;                  // which of the kRowsPerInstr rows this lane is on
-    const int cp = lane % kLanesPerRow;                   // column pair inside the tile
+    const int cl = lane % kLanesPerRow;                   // 16-byte column group inside the tile row
     const int64_t nitems = nwork * kSlabsPerTile;
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const int64_t w = it / kSlabsPerTile;
         const int slab = (int)(it - w * kSlabsPerTile);
         const int2 ij = work[w];
         const int row0 = slab * kSlab + wave * kRowsPerWave;            // first tile row of this wavefront
-        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + 2 * cp;
-        double2 v[kPasses];
+        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + kCols * cl;
+        double v[kPasses][kCols];
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
-            const V2 t = *reinterpret_cast<const V2 *>(tp + (int64_t)p * kRowsPerInstr * T);
-            v[p] = make_double2((double)t.x, (double)t.y);
+            const VL t = *reinterpret_cast<const VL *>(tp + (int64_t)p * kRowsPerInstr * T);
+            lane16_unpack(t, v[p]);
         }
-        const int64_t gcol = (int64_t)ij.y * T + 2 * cp;
+        const int64_t gcol = (int64_t)ij.y * T + kCols * cl;
         const int64_t krow = (int64_t)ij.x * T + row0;                  // wave-uniform
         for (int i = 0; i < npairs; ++i) {
             const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + (int64_t)i * pair_stride) + gcol;
             const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)i * pair_stride) + krow;
-            const double2 ga = g2[0], gb = g2[1];                       // (G1,G2) at columns 2cp and 2cp+1
+            double2 g[kCols];                                           // (G1,G2) at this lane's columns
+#pragma unroll
+            for (int q = 0; q < kCols; ++q) g[q] = g2[q];
 #pragma unroll
             for (int p = 0; p < kPasses; ++p) {
-                double2 k = k2[p * kRowsPerInstr];                      // uniform address: scalar load (T = 128)
+                double2 k = k2[p * kRowsPerInstr];                      // uniform address: scalar load when one row per instruction
                 if (kRowsPerInstr == 2) { const double2 k1 = k2[p * 2 + 1]; if (sub) k = k1; }
-                v[p].x = rank2_apply(v[p].x, k, ga);
-                v[p].y = rank2_apply(v[p].y, k, gb);
+#pragma unroll
+                for (int q = 0; q < kCols; ++q) v[p][q] = rank2_apply(v[p][q], k, g[q]);
             }
         }
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
-            V2 o;
-            o.x = (TS)v[p].x; o.y = (TS)v[p].y;
-            *reinterpret_cast<V2 *>(tp + (int64_t)p * kRowsPerInstr * T) = o;
+            VL o;
+            lane16_pack(v[p], o);
+            *reinterpret_cast<VL *>(tp + (int64_t)p * kRowsPerInstr * T) = o;
         }
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------------
 // association (Correspondence.m:49-87): one thread per landmark, block arg-min, then a one-block finish
@@ -840,9 +855,10 @@ template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, hipStream_t s) {
     int64_t grid = nwork * (T / kSlab);
     if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-    if (T >= 64)
-        hipLaunchKernelGGL((k_downdate_w<TS, (T >= 64 ? T : 64), (T >= 64 ? kSlab : 8)>), dim3((unsigned)grid), dim3(kBlock), 0, s,
-                           (TS *)st.tiles, work, nwork, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+    constexpr int kLanes = T / Lane16<TS>::kCols;
+    if constexpr (kLanes == 64 || kLanes == 32)
+        hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
+                           st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
     else
         hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
                            st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
@@ -850,23 +866,37 @@ static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64
 }
 
 // Granularity.  One pair: ONE pass per workgroup (each lane loads, updates and stores exactly one 16-byte
-// column pair; a workgroup covers 4 KiB of a tile): 6.06 TB/s at 10k landmarks vs 5.49 TB/s for a whole
-// 64x64 tile per workgroup (profiles/round1_tuning.md).  Several pairs: the G vectors are re-read from L2
-// once per workgroup and pair, so a taller slab amortises them.  EKF_DOWNDATE_SLAB /
-// EKF_DOWNDATE_SLAB_BATCH (rows per workgroup for 1 pair / several pairs) and EKF_DOWNDATE_GRID (grid cap)
-// are tuning hooks.
+// piece of a tile row; a workgroup covers 4 KiB of a tile): 6.06 TB/s at 10k landmarks vs 5.49 TB/s for a whole
+// 64x64 tile per workgroup (profiles/round1_tuning.md).  Several pairs: the G vectors are re-read from L2 once
+// per workgroup and pair, so a taller slab amortises them.  EKF_DOWNDATE_SLAB / EKF_DOWNDATE_SLAB_BATCH (rows
+// per workgroup for 1 pair / several pairs) and EKF_DOWNDATE_GRID (grid cap) are tuning hooks.
+// Production tiles: T = 128 for f64 storage, T = 256 for f32 storage (one 1 KiB tile row per wave instruction,
+// K wave-uniform); T = 16 / 32 (generic kernel) and T = 64 exist for small maps and tests.
 template <typename TS>
 static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, int slab, hipStream_t s) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
+    constexpr bool kF32 = sizeof(TS) == 4;
 #define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, npairs, grid_cap, s)
-    switch (st.tm.T) {
-        case 16: EKF_DD(16, 16);
-        case 32: if (slab == 32) EKF_DD(32, 32); EKF_DD(32, 16);
-        case 64: if (slab == 64) EKF_DD(64, 64); if (slab == 32) EKF_DD(64, 32); if (slab == 16) EKF_DD(64, 16);
-                 if (slab == 8) EKF_DD(64, 8); if (npairs > 1) EKF_DD(64, 64); EKF_DD(64, 8);
-        case 128: if (slab == 32) EKF_DD(128, 32); if (slab == 16) EKF_DD(128, 16); if (slab == 8) EKF_DD(128, 8);
-                  if (slab == 4) EKF_DD(128, 4); if (npairs > 1) EKF_DD(128, 32); EKF_DD(128, 4);
-        default: return hipErrorInvalidValue;
+    if constexpr (kF32) {
+        switch (st.tm.T) {
+            case 16: EKF_DD(16, 16);
+            case 32: EKF_DD(32, 32);
+            case 64: EKF_DD(64, 64);                 // 16 lanes per row -> generic kernel
+            case 128: if (npairs > 1) EKF_DD(128, 64); EKF_DD(128, 8);      // two rows per wave instruction
+            case 256: if (slab == 32) EKF_DD(256, 32); if (slab == 16) EKF_DD(256, 16); if (slab == 8) EKF_DD(256, 8);
+                      if (slab == 4) EKF_DD(256, 4); if (npairs > 1) EKF_DD(256, 32); EKF_DD(256, 4);
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (st.tm.T) {
+            case 16: EKF_DD(16, 16);
+            case 32: if (slab == 32) EKF_DD(32, 32); EKF_DD(32, 16);
+            case 64: if (slab == 64) EKF_DD(64, 64); if (slab == 32) EKF_DD(64, 32); if (slab == 16) EKF_DD(64, 16);
+                     if (slab == 8) EKF_DD(64, 8); if (npairs > 1) EKF_DD(64, 64); EKF_DD(64, 8);
+            case 128: if (slab == 32) EKF_DD(128, 32); if (slab == 16) EKF_DD(128, 16); if (slab == 8) EKF_DD(128, 8);
+                      if (slab == 4) EKF_DD(128, 4); if (npairs > 1) EKF_DD(128, 32); EKF_DD(128, 4);
+            default: return hipErrorInvalidValue;
+        }
     }
 #undef EKF_DD
 }

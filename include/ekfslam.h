@@ -60,7 +60,8 @@ typedef struct ekf_config {
     int32_t mode;                /* EKF_MODE_*  (selects the ekf_measure dispatch)                  */
     int32_t storage;             /* EKF_STORE_*                                                     */
     int32_t device;              /* HIP device ordinal                                              */
-    int32_t tile;                /* tile edge T in elements: 16, 32, 64 or 128; 0 = default (128)   */
+    int32_t tile;                /* tile edge T in elements: 16, 32, 64, 128 (256 for F32 storage);
+                                    0 = default (128 for F64 storage, 256 for F32 storage)           */
     int32_t rank;                /* shard rank  (0 when world == 1)                                 */
     int32_t world;               /* number of shards P is split over; 0 or 1 = unsharded            */
     int32_t batch;               /* deferred downdate: up to `batch` corrections are kept as pending rank-2
