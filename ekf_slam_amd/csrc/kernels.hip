@@ -138,6 +138,55 @@ __global__ __launch_bounds__(kBlock) void k_predict(DevState st, PredictArgs a) 
     }
 }
 
+// The strip part of P <- F P F' as a panel product on the F64 matrix cores: (F P)(1:3, landmark columns) =
+// F_rr (3x3) * strip (3 x 2N).  One v_mfma_f64_16x16x4_f64 per wavefront and 16 columns: A = F_rr zero-padded to
+// 16x4 (lane l holds A[l&15][l>>4]), B = a 4x16 slice of the strip with a zero 4th row (lane l holds
+// B[l>>4][l&15]), D row (l>>4) + 4*reg, column l&15 -> register 0 of lanes 0..47 is the new 3x16 slice.
+// The f64 MFMA is NOT a k-ordered FMA chain: against predict_strip()'s fma(fa, s2, s0) it differs in the last bit
+// for about one entry in six (measured, tests/test_deferred_gpu.py), i.e. the two predict paths agree to
+// rounding (1e-15), not bit for bit.  The panel is 3 x 2N and costs < 1 % of an update-step, so this is about
+// using the matrix unit for the one GEMM-shaped piece of the path, not about speed.
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kBlock) void k_predict_mfma(DevState st, PredictArgs a) {
+    __shared__ PredictSmall ps;
+    const int cur = a.cur, nxt = cur ^ 1;
+    const double *__restrict__ x = st.x[cur];
+    double *__restrict__ xn = st.x[nxt];
+    if (threadIdx.x == 0) {
+        const double pose[3] = { x[0], x[1], x[2] };
+        double prr[9];
+        for (int i = 0; i < 9; ++i) prr[i] = st.prr[cur][i];
+        predict_small(pose, prr, a.u0, a.u1, a.C, ps);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, jj = lane & 15;                 // k index of the A/B operands, column within the slice
+    // A[i][k], i = lane & 15 (rows 3..15 are zero padding), k = lane >> 4
+    double av = 0.0;
+    if (jj < 3) {
+        if (kk == jj) av = 1.0;
+        else if (kk == 2 && jj == 0) av = ps.fa;
+        else if (kk == 2 && jj == 1) av = ps.fb;
+    }
+    const double *__restrict__ s = st.strip[cur];
+    double *__restrict__ sn = st.strip[nxt];
+    const int64_t nslices = (a.n_mm + 15) / 16;
+    for (int64_t sl = (int64_t)blockIdx.x * 4 + wave; sl < nslices; sl += (int64_t)gridDim.x * 4) {
+        const int64_t c = sl * 16 + jj;
+        const bool live = c < a.n_mm;
+        const double bv = (kk < 3 && live) ? s[kk * st.ldm + c] : 0.0;
+        const mfma_f64x4 zero = { 0.0, 0.0, 0.0, 0.0 };
+        const mfma_f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, zero, 0, 0, 0);
+        if (kk < 3 && live) sn[kk * st.ldm + c] = d[0];
+        if (kk == 3 && live) xn[3 + c] = x[3 + c];            // the otherwise idle quarter copies the landmark states
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < 9; ++i) { st.prr[nxt][i] = ps.prr[i]; st.small[12 + i] = ps.Q[i]; }
+        for (int i = 0; i < 3; ++i) xn[i] = ps.pose[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // append: in place on buffer `cur` (only new slots are written)
 // ---------------------------------------------------------------------------------------------------
@@ -790,6 +839,16 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
     do { if ((storage) == 0) { EXPR_F64; } else { EXPR_F32; } } while (0)
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int, hipStream_t s) {
+    // MFMA panel product at large landmark counts (EKF_PREDICT_MFMA=0/1 forces the VALU / MFMA kernel)
+    static const int force = [] { const char *v = getenv("EKF_PREDICT_MFMA"); return v ? atoi(v) : -1; }();
+    const bool mfma = force >= 0 ? force != 0 : a.n_mm >= 2048;
+    if (mfma) {
+        const int64_t nslices = (a.n_mm + 15) / 16;
+        int64_t grid = cdiv(nslices > 0 ? nslices : 1, 4);
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_predict_mfma, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a);
+        return hipGetLastError();
+    }
     const int64_t grid = cdiv(a.n_mm > 0 ? a.n_mm : 1, kBlock);
     hipLaunchKernelGGL(k_predict, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a);
     return hipGetLastError();

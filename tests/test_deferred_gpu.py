@@ -142,3 +142,34 @@ def test_fused_predict_equals_standalone_predict_bitwise(oracle_lib):
     np.testing.assert_array_equal(fused.get_x(), split.get_x())
     np.testing.assert_array_equal(fused.get_P(), split.get_P())
     assert rel_err(fused.get_P(), ref.P) < REL and rel_err(fused.get_x(), ref.x) < REL
+
+
+def test_mfma_predict_panel_matches_valu_and_oracle(oracle_lib):
+    """At >= 1024 landmarks the standalone predict runs its 3x3 * 3x2N panel product on v_mfma_f64_16x16x4_f64; the
+    predict folded into a correction uses plain FMAs.  The f64 MFMA is not a k-ordered FMA chain (measured: results
+    differ from fma(fa, s2, s0) in the last bit for ~1 in 6 entries), so the two paths agree to rounding, not bit for
+    bit; both are far inside the 1e-6 tolerance against the oracle."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 1100                                        # 2200 strip columns: MFMA path, ragged last 16-column slice
+    x, P, s = _state(N, 59)
+    fused = Engine(capacity=N, batch=2)
+    split = Engine(capacity=N, batch=2)
+    ref = StructuredEKF(N, "known")
+    for e in (fused, split, ref):
+        e.set_state(x, P, s)
+    rng = np.random.default_rng(3)
+    for step in range(5):
+        u = [0.3 + 0.1 * step, 17.0 * step - 20.0]
+        fused.predict(u); split.predict(u); ref.predict(u)
+        split.get_x()                               # materialises the predict: k_predict_mfma
+        idx0 = int(rng.integers(0, N))
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        fused.correct(z, R, idx0); split.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+    fused.predict([0.2, 5.0]); split.predict([0.2, 5.0]); ref.predict([0.2, 5.0])
+    Pf, Ps = fused.get_P(), split.get_P()
+    assert rel_err(fused.get_x(), split.get_x()) < 1e-12 and rel_err(Pf, Ps) < 1e-12
+    assert rel_err(Pf, ref.P) < REL and rel_err(fused.get_x(), ref.x) < REL
+    assert rel_err(Ps, ref.P) < REL and rel_err(split.get_x(), ref.x) < REL
+    print("mfma vs valu: x %.2e P %.2e; vs oracle P %.2e" % (rel_err(fused.get_x(), split.get_x()), rel_err(Pf, Ps), rel_err(Ps, ref.P)))
