@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -70,6 +71,7 @@ struct ekf_handle {
     // instead of two, identical arithmetic); any other consumer of x / P launches k_predict first
     bool have_pp = false;
     PredictArgs pp;
+    std::vector<double> s_host;   // host mirror of the signatures (they only change through host calls)
     DevState st;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // work list of owned lower-triangle tiles for the active tile rows
@@ -230,6 +232,8 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
         TimedLaunch tl(h, EKF_KERNEL_APPEND);
         HIPCHK(h, launch_append(h->st, a, h->storage, h->stream));
     }
+    if ((int64_t)h->s_host.size() > h->N) h->s_host.resize((size_t)h->N);
+    h->s_host.push_back(signature);
     h->N += 1;
     return EKF_OK;
 }
@@ -330,6 +334,19 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     *is_new = h->h_decision->is_new;
     *idx = h->h_decision->index;
     return EKF_OK;
+}
+
+// Correspondence.m:40-43,71,75,78-85 with the live likelihood (signature cost only)
+void associate_signature_only(const ekf_handle *h, double z3, int32_t *is_new, int64_t *idx) {
+    const int64_t N = h->N;
+    *is_new = 1; *idx = N;
+    double best = INFINITY;
+    const double inv_cost = 1.0 / h->cfg.s_cost;
+    for (int64_t k = 0; k < N; ++k) {
+        const double d = z3 - h->s_host[(size_t)k];
+        const double ll = d * inv_cost * d;
+        if (ll <= h->cfg.s_thresh && ll < best) { *is_new = 0; best = ll; *idx = k; }
+    }
 }
 
 // landmark(find([landmark.index] == key)).loc  (key < 0: find([landmark.index]), i.e. all non-zero indices)
@@ -594,8 +611,17 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
         } else {
             int32_t is_new = 0;
             int64_t idx = 0;
-            rc = do_associate(h, z, R, &is_new, &idx, nullptr, nullptr);   // EKF_SLAM_UC.m:119
-            if (rc) return rc;
+            static const bool force_dev = [] { const char *v = getenv("EKF_FORCE_DEVICE_ASSOC"); return v && atoi(v) != 0; }();
+            if (h->cfg.w_pos == 0.0 && !force_dev) {
+                // The reference's decision is a pure function of z(3) and s: the Mahalanobis position cost it also
+                // evaluates is discarded (Correspondence.m:74-75).  With w_pos == 0 measure() therefore decides from
+                // the host mirror of s -- same arithmetic as k_associate, no launch, no device->host sync.
+                // ekf_associate() always runs the full device computation.
+                associate_signature_only(h, z[2], &is_new, &idx);
+            } else {
+                rc = do_associate(h, z, R, &is_new, &idx, nullptr, nullptr);   // EKF_SLAM_UC.m:119
+                if (rc) return rc;
+            }
             if (is_new) {                                                  // EKF_SLAM_UC.m:121-123
                 rc = lookup_loc(h, lm_index, lm_loc, L, false, (double)(idx + 1), loc);
                 if (rc) return rc;
@@ -730,6 +756,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
         HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
     }
     h->N = (n - 3) / 2;
+    h->s_host.resize((size_t)h->N, 0.0);
     HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return EKF_OK;
@@ -751,6 +778,7 @@ int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
     if (rc) return rc;
     if (N > 0) HIPCHK(h, hipMemcpyAsync(h->st.s, s, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->s_host.assign(s, s + N);
     return EKF_OK;
 }
 
@@ -828,6 +856,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
         HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
     }
     h->N = N;
+    h->s_host.assign(s, s + N);
     h->npend = 0;              // the whole state is replaced
     rc = refresh_work(h);
     if (rc) return rc;
