@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -77,6 +78,10 @@ struct ekf_handle {
     // work list of owned lower-triangle tiles for the active tile rows
     int2 *d_work = nullptr;
     int64_t nwork = 0, work_rows = -1, work_cap = 0;
+    // the same tiles arranged as 8 per-XCD streams of super-tiles (batched flush: keeps each XCD's K/G working set
+    // inside its own 4 MiB L2); stream x is work_xcd[x * xcd_len .. ), padded with (-1,-1)
+    int2 *d_work_xcd = nullptr;
+    int64_t xcd_len = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
@@ -152,6 +157,37 @@ int32_t refresh_work(ekf_handle *h) {
     }
     h->nwork = (int64_t)w.size();
     h->work_rows = nt;
+
+    // per-XCD streams: super-tiles of S x S tiles, largest first onto the least loaded stream
+    static const int S = [] { const char *v = getenv("EKF_SUPERTILE"); const int x = v ? atoi(v) : 8; return x < 1 ? 1 : x; }();
+    struct Super { int64_t si, sj; std::vector<int2> tiles; };
+    std::vector<Super> supers;
+    const int64_t ns = (nt + S - 1) / S;
+    for (int64_t si = 0; si < ns; ++si)
+        for (int64_t sj = 0; sj <= si; ++sj) {
+            Super sp; sp.si = si; sp.sj = sj;
+            for (int64_t I = si * S; I < nt && I < (si + 1) * S; ++I)
+                for (int64_t J = sj * S; J <= I && J < (sj + 1) * S; ++J)
+                    if (h->st.tm.mine(I, J)) sp.tiles.push_back(make_int2((int)I, (int)J));
+            if (!sp.tiles.empty()) supers.push_back(std::move(sp));
+        }
+    std::stable_sort(supers.begin(), supers.end(), [](const Super &a, const Super &b) { return a.tiles.size() > b.tiles.size(); });
+    std::vector<int2> stream[8];
+    for (const Super &sp : supers) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x) if (stream[x].size() < stream[best].size()) best = x;
+        stream[best].insert(stream[best].end(), sp.tiles.begin(), sp.tiles.end());
+    }
+    size_t len = 0;
+    for (int x = 0; x < 8; ++x) len = std::max(len, stream[x].size());
+    REQUIRE(h, (int64_t)(8 * len) <= 8 * h->work_cap, EKF_ERR_STATE, "XCD work list overflow");
+    std::vector<int2> flat(8 * len, make_int2(-1, -1));
+    for (int x = 0; x < 8; ++x) std::copy(stream[x].begin(), stream[x].end(), flat.begin() + x * len);
+    if (!flat.empty()) {
+        HIPCHK(h, hipMemcpyAsync(h->d_work_xcd, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    h->xcd_len = (int64_t)len;
     return EKF_OK;
 }
 
@@ -184,7 +220,8 @@ int32_t flush_pending(ekf_handle *h) {
     if (rc) return rc;
     {
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
-        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->npend, h->storage, h->grid_cap, h->stream));
+        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->npend, h->storage, h->grid_cap,
+                                  h->stream));
     }
     h->npend = 0;
     return EKF_OK;
@@ -462,6 +499,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->st.Kp, (size_t)(2 * ldm) * h->batch));
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
+    HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));
     HIPCHK(h, dalloc(h, &h->d_partial, (size_t)((h->cap + kAssocBlock - 1) / kAssocBlock)));
     HIPCHK(h, dalloc(h, &h->d_decision, 1));
     HIPCHK(h, dalloc(h, &h->d_pos_cost, (size_t)h->cap));

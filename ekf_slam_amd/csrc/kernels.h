@@ -80,8 +80,10 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
                                  int64_t slab, int storage, hipStream_t s);
 // tiles -= sum_{i < npairs} K_i G_i (in slot order) over the work list (I,J pairs, device array) of `nwork` owned
 // lower-triangle tiles: ONE pass over P for npairs update-steps
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int npairs, int storage, int grid_cap,
-                           hipStream_t s);
+// work_xcd / xcd_len: the same tiles as 8 per-XCD streams (stream x = work_xcd[x*xcd_len ..), padded with (-1,-1)),
+// used when several pairs are applied so that each XCD's K/G working set stays inside its own L2
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                           int npairs, int storage, int grid_cap, hipStream_t s);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s);

@@ -305,12 +305,22 @@ struct PanelView {
     }
 };
 
-// Each shard copies the chunks of M it owns (canonical lower-triangle entries) into its send slab.
+constexpr int kMaxPending = 64;        // cfg.batch upper bound (LDS staging of the wave-uniform patch operands)
+
+// Each shard copies the chunks of M it owns (canonical lower-triangle entries, patched with the pending pairs in
+// slot order exactly like the unsharded gather does) into its send slab.
 template <typename TS>
 __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int npend,
                                                      double *__restrict__ send, int64_t nchunks_local) {
+    __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const TileMap &tm = st.tm;
     const TS *__restrict__ tiles = (const TS *)st.tiles;
+    for (int e = threadIdx.x; e < 4 * npend; e += kBlock) {
+        const int i = e >> 2, which = e & 3;
+        const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)i * st.pair_stride;
+        upatch[e] = reinterpret_cast<const double2 *>(base)[j + (which & 1)];
+    }
+    __syncthreads();
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // local column: kl * T + cc
     if (e >= (nchunks_local << tm.shift)) return;
     const int64_t Ij = j >> tm.shift;
@@ -318,11 +328,38 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
     const int64_t kl = e >> tm.shift, cc = e & (tm.T - 1);
     const int64_t c = ((k0 + kl * tm.world) << tm.shift) + cc;
     double m0 = 0.0, m1 = 0.0;
-    if (c < n_mm) { m0 = pmm_live<TS>(tiles, st, npend, j, c); m1 = pmm_live<TS>(tiles, st, npend, j + 1, c); }
+    const int64_t ps2 = st.pair_stride / 2;
+    if (c < n_mm) {
+        if (c <= j) {
+            m0 = pmm_low<TS>(tiles, tm, j, c);
+            m1 = pmm_low<TS>(tiles, tm, j + 1, c);
+            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
+            for (int i = 0; i < npend; ++i) {
+                const double2 g = gp[(int64_t)i * ps2];
+                m0 = rank2_apply(m0, upatch[4 * i + 0], g);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], g);
+            }
+        } else if (c >= j + 2) {
+            m0 = pmm_low<TS>(tiles, tm, c, j);
+            m1 = pmm_low<TS>(tiles, tm, c, j + 1);
+            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
+            for (int i = 0; i < npend; ++i) {
+                const double2 k = kp[(int64_t)i * ps2];
+                m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
+            }
+        } else {                                                   // c == j + 1: canonical (j+1,j) and (j+1,j+1)
+            m0 = pmm_low<TS>(tiles, tm, j + 1, j);
+            m1 = pmm_low<TS>(tiles, tm, j + 1, j + 1);
+            for (int i = 0; i < npend; ++i) {
+                m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+            }
+        }
+    }
     reinterpret_cast<double2 *>(send)[e] = make_double2(m0, m1);
 }
 
-constexpr int kMaxPending = 64;        // cfg.batch upper bound (LDS staging of the wave-uniform patch operands)
 
 template <typename TS, bool kSharded, bool kPredict>
 __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
@@ -563,7 +600,7 @@ __device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
     t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
 }
 
-template <typename TS, int T, int kSlab>
+template <typename TS, int T, int kSlab, bool kXcd>
 __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, const int2 *__restrict__ work,
                                                        int64_t nwork, const double *__restrict__ Kp,
                                                        const double *__restrict__ Gp, int64_t pair_stride, int npairs,
@@ -581,11 +618,16 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, c
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = lane / kLanesPerRow;                  // which of the kRowsPerInstr rows this lane is on
     const int cl = lane % kLanesPerRow;                   // 16-byte column group inside the tile row
-    const int64_t nitems = nwork * kSlabsPerTile;
+    // kXcd: `work` holds 8 streams of `nwork` tiles each (padded with (-1,-1)); workgroups b and b+8 run on the same
+    // XCD (round-robin dispatch -- a speed assumption only), so workgroup b walks stream b % 8 and the XCD's
+    // resident workgroups stay inside one or two super-tiles whose K/G slices fit its L2.
+    const int64_t nitems = (kXcd ? 8 : 1) * nwork * kSlabsPerTile;
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t w = it / kSlabsPerTile;
-        const int slab = (int)(it - w * kSlabsPerTile);
-        const int2 ij = work[w];
+        const int64_t vi = kXcd ? (it >> 3) : it;
+        const int64_t w = vi / kSlabsPerTile;
+        const int slab = (int)(vi - w * kSlabsPerTile);
+        const int2 ij = work[kXcd ? (it & 7) * nwork + w : w];
+        if (kXcd && ij.x < 0) continue;
         const int row0 = slab * kSlab + wave * kRowsPerWave;            // first tile row of this wavefront
         TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + kCols * cl;
         double v[kPasses][kCols];
@@ -911,16 +953,28 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 }
 
 template <typename TS, int T, int kSlab>
-static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, hipStream_t s) {
-    int64_t grid = nwork * (T / kSlab);
-    if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                                     int npairs, int grid_cap, hipStream_t s) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
-    if constexpr (kLanes == 64 || kLanes == 32)
-        hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
-                           st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
-    else
+    static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
+    if constexpr (kLanes == 64 || kLanes == 32) {
+        if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
+            int64_t grid = 8 * xcd_len * (T / kSlab);
+            if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles,
+                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+        } else {
+            int64_t grid = nwork * (T / kSlab);
+            if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles,
+                               work, nwork, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+        }
+    } else {
+        int64_t grid = nwork * (T / kSlab);
+        if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
                            st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+    }
     return hipGetLastError();
 }
 
@@ -932,10 +986,11 @@ static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64
 // Production tiles: T = 128 for f64 storage, T = 256 for f32 storage (one 1 KiB tile row per wave instruction,
 // K wave-uniform); T = 16 / 32 (generic kernel) and T = 64 exist for small maps and tests.
 template <typename TS>
-static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, int npairs, int grid_cap, int slab, hipStream_t s) {
+static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                                    int npairs, int grid_cap, int slab, hipStream_t s) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, npairs, grid_cap, s)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, s)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -960,13 +1015,13 @@ static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_
 #undef EKF_DD
 }
 
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, int npairs, int storage, int grid_cap,
-                           hipStream_t s) {
+hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                           int npairs, int storage, int grid_cap, hipStream_t s) {
     static const int slab1 = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
     static const int slabm = [] { const char *v = getenv("EKF_DOWNDATE_SLAB_BATCH"); return v ? atoi(v) : 0; }();
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, npairs, grid_cap, slab, s)
-                        : launch_downdate_t<float>(st, work, nwork, npairs, grid_cap, slab, s);
+    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, slab, s)
+                        : launch_downdate_t<float>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, slab, s);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
