@@ -56,6 +56,9 @@ SIGNATURES = {
     "ekf_comm_init": (_i32, [_vp, ctypes.c_char_p]),
     "ekf_correct_begin": (_i32, [_vp, _dp, _dp, _i64]),
     "ekf_correct_finish": (_i32, [_vp]),
+    "ekf_prefetch_rows": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),
+    "ekf_prefetch_begin": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),
+    "ekf_prefetch_finish": (_i32, [_vp]),
     "ekf_exchange_info": (_i32, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64),
                                  ctypes.POINTER(_i64)]),
     "ekf_exchange_set_buffers": (_i32, [_vp, _vp, _vp]),

@@ -90,8 +90,16 @@ struct ekf_handle {
     double *own_send = nullptr, *own_recv = nullptr, *send = nullptr, *recv = nullptr;
     int64_t slab_cap = 0;          // doubles per shard slab at capacity
     int64_t slab = 0;              // doubles per shard slab of the pending correction
-    bool pending = false;
+    bool pending = false;          // an exchange is between begin and finish ...
+    int pending_kind = 0;          // ... 1: one correction's row-panel, 2: a prefetch of several base row-panels
+    int64_t x_count = 0;           // doubles per shard of the pending exchange
     CorrectArgs pending_args;
+    // prefetched BASE row-panels (ekf_prefetch_rows): valid until the tiles change (flush) or the map grows
+    bool pf_valid = false;
+    int32_t pf_m = 0;
+    int64_t pf_slab = 0, pf_N = 0;
+    std::vector<int64_t> pf_idx;
+    double *pf_store = nullptr;    // world x batch x slab_cap
     void *comm = nullptr;          // ncclComm_t
     KernelTimer timers[EKF_KERNEL_COUNT];
     std::vector<void *> allocs;
@@ -224,6 +232,7 @@ int32_t flush_pending(ekf_handle *h) {
                                   h->stream));
     }
     h->npend = 0;
+    h->pf_valid = false;       // the prefetched row-panels were base values of the old tiles
     return EKF_OK;
 }
 
@@ -272,6 +281,7 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     if ((int64_t)h->s_host.size() > h->N) h->s_host.resize((size_t)h->N);
     h->s_host.push_back(signature);
     h->N += 1;
+    h->pf_valid = false;
     return EKF_OK;
 }
 
@@ -281,46 +291,103 @@ int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
     return cmax * h->T * 2;
 }
 
-int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
-    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
-    REQUIRE(h, !h->pending, EKF_ERR_STATE, "correct_begin: a correction is already pending");
-    int32_t rc = refresh_work(h);
-    if (rc) return rc;
-    CorrectArgs &a = h->pending_args;
-    a.z0 = z[0]; a.z1 = z[1];
-    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
-    h->slab = slab_for(h, a.n_mm);
-    HIPCHK(h, launch_rowpanel(h->st, a.j, a.n_mm, h->npend, h->send, h->storage, h->stream));
-    h->pending = true;
-    return EKF_OK;
-}
-
-int32_t correct_finish(ekf_handle *h) {
-    REQUIRE(h, h->pending, EKF_ERR_STATE, "correct_finish: no correction pending");
-    h->pending = false;
-    {
-        TimedLaunch tl(h, EKF_KERNEL_GATHER);
-        const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
-        HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, fuse, h->recv, h->slab, h->storage, h->stream));
-        h->have_pp = false;
-    }
+int32_t finish_step(ekf_handle *h) {
     h->cur ^= 1;
     h->npend += 1;
     return h->npend >= h->batch ? flush_pending(h) : EKF_OK;
 }
 
+void fill_correct_args(ekf_handle *h, CorrectArgs &a, const double z[2], const double R[4], int64_t idx) {
+    a.z0 = z[0]; a.z1 = z[1];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
+}
+
+// slot of landmark idx among the prefetched base row-panels, or -1
+int prefetch_slot(const ekf_handle *h, int64_t idx) {
+    if (!h->pf_valid || h->pf_N != h->N) return -1;
+    for (int q = 0; q < h->pf_m; ++q) if (h->pf_idx[(size_t)q] == idx) return q;
+    return -1;
+}
+
+int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
+    REQUIRE(h, !h->pending, EKF_ERR_STATE, "correct_begin: an exchange is already pending");
+    int32_t rc = refresh_work(h);
+    if (rc) return rc;
+    fill_correct_args(h, h->pending_args, z, R, idx);
+    h->slab = slab_for(h, h->pending_args.n_mm);
+    HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->npend, h->send, h->storage, h->stream));
+    h->pending = true; h->pending_kind = 1; h->x_count = h->slab;
+    return EKF_OK;
+}
+
+int32_t correct_finish(ekf_handle *h) {
+    REQUIRE(h, h->pending && h->pending_kind == 1, EKF_ERR_STATE, "correct_finish: no correction pending");
+    h->pending = false; h->pending_kind = 0;
+    {
+        TimedLaunch tl(h, EKF_KERNEL_GATHER);
+        const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+        HIPCHK(h, launch_gather_sharded(h->st, h->pending_args, fuse, h->recv, h->slab, 0, /*patched*/ true, h->storage,
+                                        h->stream));
+        h->have_pp = false;
+    }
+    return finish_step(h);
+}
+
+// copy the BASE row-panels (no pending pairs applied: they are applied at correction time) of m landmarks into
+// the send buffer; after the all-gather the corrections on these landmarks need no exchange of their own
+int32_t prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
+    REQUIRE(h, !h->pending, EKF_ERR_STATE, "prefetch_begin: an exchange is already pending");
+    REQUIRE(h, m >= 1 && m <= h->batch, EKF_ERR_INVALID_ARG, "prefetch: between 1 and cfg.batch landmarks");
+    for (int32_t q = 0; q < m; ++q)
+        REQUIRE(h, idx[q] >= 0 && idx[q] < h->N, EKF_ERR_INDEX, "prefetch: landmark index outside the state");
+    const int64_t slab = slab_for(h, n_mm(h));
+    for (int32_t q = 0; q < m; ++q)
+        HIPCHK(h, launch_rowpanel(h->st, 2 * idx[q], n_mm(h), /*npend*/ 0, h->send + (size_t)q * slab, h->storage, h->stream));
+    h->pf_valid = false;
+    h->pf_idx.assign(idx, idx + m);
+    h->pf_m = m; h->pf_slab = slab; h->pf_N = h->N;
+    h->pending = true; h->pending_kind = 2; h->x_count = (int64_t)m * slab;
+    return EKF_OK;
+}
+
+int32_t prefetch_finish(ekf_handle *h) {
+    REQUIRE(h, h->pending && h->pending_kind == 2, EKF_ERR_STATE, "prefetch_finish: no prefetch pending");
+    h->pending = false; h->pending_kind = 0;
+    HIPCHK(h, hipMemcpyAsync(h->pf_store, h->recv, (size_t)h->x_count * h->cfg.world * sizeof(double),
+                             hipMemcpyDeviceToDevice, h->stream));
+    h->pf_valid = true;
+    return EKF_OK;
+}
+
 int32_t exchange_rccl(ekf_handle *h) {
     REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
-            "sharded handle without a communicator: call ekf_comm_init, or drive ekf_correct_begin / your own "
-            "all-gather / ekf_correct_finish");
-    const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->slab, /*ncclDouble*/ 8, h->comm, h->stream);
+            "sharded handle without a communicator: call ekf_comm_init, or drive the begin / your own all-gather / "
+            "finish calls");
+    const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
     if (r != 0) { h->pending = false; return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r)); }
     return EKF_OK;
 }
 
 int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
     if (h->sharded) {
+        REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
+        const int q = prefetch_slot(h, idx);
+        if (q >= 0 && slab_for(h, n_mm(h)) == h->pf_slab) {
+            // base row-panel already on every shard: no exchange, pending pairs applied inside the gather
+            REQUIRE(h, !h->pending, EKF_ERR_STATE, "correct: an exchange is pending");
+            CorrectArgs a;
+            fill_correct_args(h, a, z, R, idx);
+            {
+                TimedLaunch tl(h, EKF_KERNEL_GATHER);
+                const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+                HIPCHK(h, launch_gather_sharded(h->st, a, fuse, h->pf_store, (int64_t)h->pf_m * h->pf_slab, (int64_t)q * h->pf_slab,
+                                                /*patched*/ false, h->storage, h->stream));
+                h->have_pp = false;
+            }
+            return finish_step(h);
+        }
         int32_t rc = correct_begin(h, z, R, idx);
         if (rc) return rc;
         rc = exchange_rccl(h);
@@ -331,18 +398,14 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     int32_t rc = refresh_work(h);
     if (rc) return rc;
     CorrectArgs a;
-    a.z0 = z[0]; a.z1 = z[1];
-    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
+    fill_correct_args(h, a, z, R, idx);
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
         HIPCHK(h, launch_gather(h->st, a, fuse, h->storage, h->stream));
         h->have_pp = false;
     }
-    h->cur ^= 1;
-    h->npend += 1;
-    return h->npend >= h->batch ? flush_pending(h) : EKF_OK;
+    return finish_step(h);
 }
 
 int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
@@ -510,8 +573,10 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         h->sharded = world > 1 || (fs && atoi(fs) != 0);
         if (h->sharded) {
             h->slab_cap = slab_for(h, 2 * h->cap);
-            HIPCHK(h, dalloc(h, &h->own_send, (size_t)h->slab_cap));
-            HIPCHK(h, dalloc(h, &h->own_recv, (size_t)(h->slab_cap * world)));
+            const size_t rows = (size_t)(cfg->batch < 1 ? 1 : cfg->batch);     // a prefetch carries up to `batch` row-panels
+            HIPCHK(h, dalloc(h, &h->own_send, (size_t)h->slab_cap * rows));
+            HIPCHK(h, dalloc(h, &h->own_recv, (size_t)h->slab_cap * rows * world));
+            HIPCHK(h, dalloc(h, &h->pf_store, (size_t)h->slab_cap * rows * world));
             h->send = h->own_send;
             h->recv = h->own_recv;
         }
@@ -630,6 +695,25 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
         return fail(h, EKF_ERR_INVALID_ARG, "measure: bad argument");
     int32_t rc = use_device(h);
     if (rc) return rc;
+    if (h->sharded && h->comm && h->batch > 1 && m > 1 && h->N > 0) {
+        // the scan's corrections are known before the loop runs: fetch their base row-panels in ONE exchange
+        // (rows that turn out to append drop the prefetch again; the per-row exchange then takes over)
+        std::vector<int64_t> want;
+        for (int64_t ii = 0; ii < m && (int64_t)want.size() < h->batch; ++ii) {
+            int64_t idx = -1;
+            if (h->cfg.mode == EKF_MODE_KNOWN) { if (!(obs[2 * m + ii] > (double)h->N) && ii < h->N) idx = ii; }
+            else if (h->cfg.w_pos == 0.0) { int32_t nw = 0; associate_signature_only(h, obs[2 * m + ii], &nw, &idx); if (nw) idx = -1; }
+            if (idx >= 0 && std::find(want.begin(), want.end(), idx) == want.end()) want.push_back(idx);
+        }
+        if (want.size() > 1) {
+            rc = prefetch_begin(h, want.data(), (int32_t)want.size());     // reads tiles only: a lazy predict stays lazy
+            if (rc) return rc;
+            rc = exchange_rccl(h);
+            if (rc) { h->pending = false; return rc; }
+            rc = prefetch_finish(h);
+            if (rc) return rc;
+        }
+    }
     for (int64_t ii = 0; ii < m; ++ii) {                                   // EKF_SLAM.m:107
         const double z[3] = { obs[ii], obs[m + ii], obs[2 * m + ii] };
         const double R[4] = { z[0] * h->cfg.Rc[0], 0.0, 0.0, z[1] * h->cfg.Rc[1] };   // :108
@@ -686,13 +770,38 @@ int32_t ekf_correct_finish(ekf_handle *h) {
     return rc ? rc : correct_finish(h);
 }
 
+int32_t ekf_prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
+    if (!h || !idx) return fail(h, EKF_ERR_INVALID_ARG, "prefetch_begin: null argument");
+    REQUIRE(h, h->sharded, EKF_ERR_STATE, "prefetch_begin: handle is not sharded");
+    int32_t rc = use_device(h);
+    return rc ? rc : prefetch_begin(h, idx, m);
+}
+
+int32_t ekf_prefetch_finish(ekf_handle *h) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    int32_t rc = use_device(h);
+    return rc ? rc : prefetch_finish(h);
+}
+
+int32_t ekf_prefetch_rows(ekf_handle *h, const int64_t *idx, int32_t m) {
+    if (!h || !idx) return fail(h, EKF_ERR_INVALID_ARG, "prefetch_rows: null argument");
+    if (!h->sharded) return EKF_OK;                  // nothing to exchange on an unsharded handle
+    int32_t rc = use_device(h);
+    if (rc) return rc;
+    rc = prefetch_begin(h, idx, m);
+    if (rc) return rc;
+    rc = exchange_rccl(h);
+    if (rc) { h->pending = false; return rc; }
+    return prefetch_finish(h);
+}
+
 int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity) {
     if (!h) return EKF_ERR_INVALID_ARG;
     REQUIRE(h, h->sharded, EKF_ERR_STATE, "exchange_info: handle is not sharded");
     if (send) *send = h->send;
     if (recv) *recv = h->recv;
-    if (count) *count = h->slab;
-    if (count_capacity) *count_capacity = h->slab_cap;
+    if (count) *count = h->pending ? h->x_count : h->slab;
+    if (count_capacity) *count_capacity = h->slab_cap * h->batch;
     return EKF_OK;
 }
 
@@ -709,20 +818,20 @@ int32_t ekf_exchange_local(ekf_handle **hs, int32_t world) {
     for (int r = 0; r < world; ++r) {
         if (!hs[r]) return EKF_ERR_INVALID_ARG;
         REQUIRE(hs[r], hs[r]->sharded && hs[r]->cfg.world == world && hs[r]->cfg.rank == r && hs[r]->pending &&
-                           hs[r]->slab == hs[0]->slab,
-                EKF_ERR_STATE, "exchange_local: handles must be the shards 0..world-1 of one filter, each with a pending correction");
+                           hs[r]->x_count == hs[0]->x_count && hs[r]->pending_kind == hs[0]->pending_kind,
+                EKF_ERR_STATE, "exchange_local: handles must be the shards 0..world-1 of one filter, each between the same begin and finish");
     }
     // producers first: every shard's send slab must be complete before anyone copies it
     for (int r = 0; r < world; ++r) {
         HIPCHK(hs[r], hipSetDevice(hs[r]->cfg.device));
         HIPCHK(hs[r], hipStreamSynchronize(hs[r]->stream));
     }
-    const size_t bytes = (size_t)hs[0]->slab * sizeof(double);
+    const size_t bytes = (size_t)hs[0]->x_count * sizeof(double);
     for (int dst = 0; dst < world; ++dst) {
         ekf_handle *d = hs[dst];
         HIPCHK(d, hipSetDevice(d->cfg.device));
         for (int src = 0; src < world; ++src)
-            HIPCHK(d, hipMemcpyPeerAsync(d->recv + (size_t)src * d->slab, d->cfg.device, hs[src]->send,
+            HIPCHK(d, hipMemcpyPeerAsync(d->recv + (size_t)src * d->x_count, d->cfg.device, hs[src]->send,
                                          hs[src]->cfg.device, bytes, d->stream));
     }
     return EKF_OK;
@@ -939,8 +1048,17 @@ int32_t ekf_kernel_timing_enable(ekf_handle *h, int32_t which, int32_t on) {
     int32_t rc = use_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    h->timers[which].enabled = on != 0;
-    h->timers[which].used = 0;
+    KernelTimer &t = h->timers[which];
+    if (on) {
+        // create the event pool now: hipEventCreate inside a timed region costs tens of microseconds per launch
+        while (t.ev.size() < 2 * 512) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            t.ev.push_back(e);
+        }
+    }
+    t.enabled = on != 0;
+    t.used = 0;
     return EKF_OK;
 }
 

@@ -76,8 +76,10 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
 int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s);
+// recv: `world` contributions `rank_stride` doubles apart; this correction's row-panel starts `offset` doubles into
+// each; patched: the pending pairs are already applied to it (k_rowpanel) -- otherwise the gather applies them
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
-                                 int64_t slab, int storage, hipStream_t s);
+                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s);
 // tiles -= sum_{i < npairs} K_i G_i (in slot order) over the work list (I,J pairs, device array) of `nwork` owned
 // lower-triangle tiles: ONE pass over P for npairs update-steps
 // work_xcd / xcd_len: the same tiles as 8 per-XCD streams (stream x = work_xcd[x*xcd_len ..), padded with (-1,-1)),

@@ -295,12 +295,14 @@ __device__ inline void solve_small(const double *pss, double z0, double z1, doub
 // (tile_row(j) + k) mod world at local chunk k / world, interleaved (M(1,c), M(2,c)).
 struct PanelView {
     const double *recv;
-    int64_t slab;       // doubles per shard slab
+    int64_t slab;       // doubles between two shards' contributions (rank stride)
+    int64_t offset;     // doubles to this row-panel inside a shard's contribution (prefetched batches hold several)
     int64_t Ij;         // tile row of j
+    int32_t patched;    // 1: the pending pairs are already applied (k_rowpanel did it); 0: base values, patch here
     __device__ __forceinline__ double2 at(const TileMap &tm, int64_t c) const {
         const int64_t k = c >> tm.shift;
         const int64_t o = (Ij + k) % tm.world;
-        const int64_t e = o * slab + (((k / tm.world) << tm.shift) + (c & (tm.T - 1))) * 2;
+        const int64_t e = o * slab + offset + (((k / tm.world) << tm.shift) + (c & (tm.T - 1))) * 2;
         return make_double2(recv[e], recv[e + 1]);
     }
 };
@@ -375,6 +377,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     const int64_t j = a.j, ldm = st.ldm;
     const int npend = a.npend;
 
+    const bool do_patch = !kSharded || !pv.patched;       // base values in hand: apply the pending pairs here
+
     if (tid < 9) pss[tid] = st.prr[cur][tid];
     else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
     else if (tid < 19) {
@@ -383,12 +387,12 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
             const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
             pss[tid] = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
         } else {
-            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);    // base value; pending pairs applied below from LDS
+            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
         }
     }
     else if (tid < 22) pss[tid] = x[tid - 19];
     else if (tid < 24) pss[tid] = x[3 + j + (tid - 22)];
-    if (!kSharded) {
+    if (do_patch) {
         for (int e = tid; e < 4 * npend; e += kBlock) {
             const int i = e >> 2, which = e & 3;
             const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)i * st.pair_stride;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     }
     __syncthreads();
     if (tid == 0) {
-        if (!kSharded) {
+        if (do_patch) {
             // live 2x2 diagonal block: canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
             double d00 = pss[15], d10 = pss[17], d11 = pss[18];
             for (int i = 0; i < npend; ++i) {
@@ -425,59 +429,56 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + (int64_t)npend * st.pair_stride);
     if (c < a.n_mm) {
         // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part
-        // right of j+1), each patched with the pending pairs in slot order
+        // right of j+1) from the tiles or from the exchanged row-panel, patched with the pending pairs in slot order
         double m0, m1;
-        if (kSharded) {
-            const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y;
-        } else if (c <= j) {
-            m0 = pmm_low<TS>(tiles, st.tm, j, c);
-            m1 = pmm_low<TS>(tiles, st.tm, j + 1, c);
-            // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
-            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
+        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
+        else if (c <= j) { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
+        else if (c >= j + 2) { m0 = pmm_low<TS>(tiles, st.tm, c, j); m1 = pmm_low<TS>(tiles, st.tm, c, j + 1); }
+        else { m0 = pmm_low<TS>(tiles, st.tm, j + 1, j); m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1); }   // c == j + 1
+        if (do_patch) {
             const int64_t ps2 = st.pair_stride / 2;
-            int i = 0;
-            for (; i + 8 <= npend; i += 8) {
-                double2 g[8];
+            if (c <= j) {
+                // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
+                const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
+                int i = 0;
+                for (; i + 8 <= npend; i += 8) {
+                    double2 g[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)(i + q) * ps2];
+                    for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)(i + q) * ps2];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    m0 = rank2_apply(m0, upatch[4 * (i + q) + 0], g[q]);
-                    m1 = rank2_apply(m1, upatch[4 * (i + q) + 1], g[q]);
+                    for (int q = 0; q < 8; ++q) {
+                        m0 = rank2_apply(m0, upatch[4 * (i + q) + 0], g[q]);
+                        m1 = rank2_apply(m1, upatch[4 * (i + q) + 1], g[q]);
+                    }
                 }
-            }
-            for (; i < npend; ++i) {
-                const double2 g = gp[(int64_t)i * ps2];
-                m0 = rank2_apply(m0, upatch[4 * i + 0], g);
-                m1 = rank2_apply(m1, upatch[4 * i + 1], g);
-            }
-        } else if (c >= j + 2) {
-            m0 = pmm_low<TS>(tiles, st.tm, c, j);
-            m1 = pmm_low<TS>(tiles, st.tm, c, j + 1);
-            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
-            const int64_t ps2 = st.pair_stride / 2;
-            int i = 0;
-            for (; i + 8 <= npend; i += 8) {
-                double2 k[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)(i + q) * ps2];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    m0 = rank2_apply(m0, k[q], upatch[4 * (i + q) + 2]);
-                    m1 = rank2_apply(m1, k[q], upatch[4 * (i + q) + 3]);
+                for (; i < npend; ++i) {
+                    const double2 g = gp[(int64_t)i * ps2];
+                    m0 = rank2_apply(m0, upatch[4 * i + 0], g);
+                    m1 = rank2_apply(m1, upatch[4 * i + 1], g);
                 }
-            }
-            for (; i < npend; ++i) {
-                const double2 k = kp[(int64_t)i * ps2];
-                m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
-                m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
-            }
-        } else {                                                   // c == j + 1: canonical (j+1,j) and (j+1,j+1)
-            m0 = pmm_low<TS>(tiles, st.tm, j + 1, j);
-            m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1);
-            for (int i = 0; i < npend; ++i) {
-                m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
-                m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+            } else if (c >= j + 2) {
+                const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
+                int i = 0;
+                for (; i + 8 <= npend; i += 8) {
+                    double2 k[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)(i + q) * ps2];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        m0 = rank2_apply(m0, k[q], upatch[4 * (i + q) + 2]);
+                        m1 = rank2_apply(m1, k[q], upatch[4 * (i + q) + 3]);
+                    }
+                }
+                for (; i < npend; ++i) {
+                    const double2 k = kp[(int64_t)i * ps2];
+                    m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
+                    m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
+                }
+            } else {                                               // c == j + 1: canonical (j+1,j) and (j+1,j+1)
+                for (int i = 0; i < npend; ++i) {
+                    m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
+                    m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+                }
             }
         }
         double s0 = strip[c], s1 = strip[ldm + c];
@@ -910,7 +911,7 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kBlock);
     PanelView pv;
-    pv.recv = nullptr; pv.slab = 0; pv.Ij = 0;
+    pv.recv = nullptr; pv.slab = 0; pv.offset = 0; pv.Ij = 0; pv.patched = 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
 #define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)
@@ -938,11 +939,11 @@ hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npen
 }
 
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
-                                 int64_t slab, int storage, hipStream_t s) {
+                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kBlock);
     PanelView pv;
-    pv.recv = recv; pv.slab = slab; pv.Ij = a.j >> st.tm.shift;
+    pv.recv = recv; pv.slab = rank_stride; pv.offset = offset; pv.Ij = a.j >> st.tm.shift; pv.patched = patched ? 1 : 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
 #define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)

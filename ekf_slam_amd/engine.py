@@ -90,6 +90,23 @@ class Engine:
     def correct_finish(self):
         self._check(self.lib.ekf_correct_finish(self.h))
 
+    def prefetch_rows(self, idx0_list):
+        """One exchange for the base row-panels of the landmarks the next corrections touch (sharded handles)."""
+        arr = (ctypes.c_int64 * len(idx0_list))(*[int(i) for i in idx0_list])
+        if self._host_exchange is not None:
+            self._check(self.lib.ekf_prefetch_begin(self.h, arr, len(idx0_list)))
+            self._host_exchange(self)
+            self._check(self.lib.ekf_prefetch_finish(self.h))
+            return
+        self._check(self.lib.ekf_prefetch_rows(self.h, arr, len(idx0_list)))
+
+    def prefetch_begin(self, idx0_list):
+        arr = (ctypes.c_int64 * len(idx0_list))(*[int(i) for i in idx0_list])
+        self._check(self.lib.ekf_prefetch_begin(self.h, arr, len(idx0_list)))
+
+    def prefetch_finish(self):
+        self._check(self.lib.ekf_prefetch_finish(self.h))
+
     def exchange_info(self):
         send, recv = ctypes.c_void_p(), ctypes.c_void_p()
         cnt, cap = ctypes.c_int64(), ctypes.c_int64()

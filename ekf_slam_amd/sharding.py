@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 
 from . import _lib as L
-from .engine import Engine
+from .engine import Engine, _colmajor, _p, _vec
 
 
 def owner(world, I, J):
@@ -119,6 +119,25 @@ class ShardGroup:
             raise L.EkfError(rc, self.lib.ekf_last_error(self.shards[0].h).decode())
         for e in self.shards:
             e.correct_finish()
+
+    def prefetch_rows(self, idx0_list):
+        for e in self.shards:
+            e.prefetch_begin(idx0_list)
+        rc = self.lib.ekf_exchange_local(self._harr, self.world)
+        if rc:
+            raise L.EkfError(rc, self.lib.ekf_last_error(self.shards[0].h).decode())
+        for e in self.shards:
+            e.prefetch_finish()
+
+    def correct_local(self, z, R, idx0):
+        """A correction on a prefetched landmark: no exchange, each shard proceeds on its own."""
+        for e in self.shards:
+            self._chk(e, self.lib.ekf_correct(e.h, _p(_vec(z[:2], 2)), _p(_colmajor(R).reshape(-1, order="F")), int(idx0)))
+
+    @staticmethod
+    def _chk(e, rc):
+        if rc:
+            raise L.EkfError(rc, e.lib.ekf_last_error(e.h).decode())
 
     def associate(self, z, R):
         res = [e.associate(z, R) for e in self.shards]

@@ -141,8 +141,17 @@ int32_t ekf_comm_unique_id(ekf_comm_id *id);                      /* rank 0 crea
 int32_t ekf_comm_init(ekf_handle *h, const ekf_comm_id *id);      /* collective over all shards */
 int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx);
 int32_t ekf_correct_finish(ekf_handle *h);
-/* Device pointers of the exchange: send slab (*count doubles valid for the pending correction) and receive
- * area (world slabs of *count doubles, slab r from shard r); *count_capacity = largest count at capacity. */
+/* Latency hiding for hosts that know which landmarks the next corrections touch (a scan's observation list):
+ * all-gather the BASE row-panels of up to cfg.batch landmarks in ONE exchange; later corrections on them run with no
+ * exchange of their own (the pending pairs are applied inside the gather kernel).  The prefetch is dropped when P is
+ * rewritten (a flush) or the map grows.  ekf_prefetch_rows = begin + ncclAllGather + finish (transport (a)); begin /
+ * finish bracket the caller's all-gather for transports (b) and (c).  No-op on an unsharded handle. */
+int32_t ekf_prefetch_rows(ekf_handle *h, const int64_t *idx, int32_t m);
+int32_t ekf_prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m);
+int32_t ekf_prefetch_finish(ekf_handle *h);
+/* Device pointers of the exchange: send area (*count doubles valid for the pending begin) and receive area (world
+ * contributions of *count doubles, contribution r from shard r); *count_capacity = largest count at capacity
+ * (cfg.batch row-panels). */
 int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity);
 /* Use caller-owned device buffers (>= count_capacity and world * count_capacity doubles); NULL restores the own ones. */
 int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv);

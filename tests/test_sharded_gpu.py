@@ -94,9 +94,9 @@ x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, 2 * N)])
 U = rng.normal(0, 0.05, (n, 6)); P = np.diag(rng.uniform(0.01, 0.1, n)) + U @ U.T
 s = np.arange(1, N + 1.0)
 mode = sys.argv[1]
-e = Engine(capacity=N, tile=32)
+e = Engine(capacity=N, tile=32, batch=4)
 os.environ["EKF_FORCE_SHARDED"] = "0"
-ref = Engine(capacity=N, tile=32)
+ref = Engine(capacity=N, tile=32, batch=4)
 e.set_state(x, P, s); ref.set_state(x, P, s)
 if mode == "rccl":
     raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
@@ -114,6 +114,12 @@ for idx0 in (0, 50, 119, 7):
     z = [rng.uniform(1, 30), rng.uniform(1, 359)]; R = np.diag([z[0] * .01, z[1] * 5.0])
     e.predict([0.1, 3.0]); ref.predict([0.1, 3.0])
     e.correct(z, R, idx0); ref.correct(z, R, idx0)
+# one exchange for the next three corrections, then a whole scan through measure() (which prefetches by itself)
+e.prefetch_rows([3, 60, 61])
+for idx0 in (60, 3, 61):
+    z = [rng.uniform(1, 30), rng.uniform(1, 359)]; R = np.diag([z[0] * .01, z[1] * 5.0])
+    e.predict([0.1, 3.0]); ref.predict([0.1, 3.0])
+    e.correct(z, R, idx0); ref.correct(z, R, idx0)
 np.testing.assert_array_equal(e.get_P(), ref.get_P())
 np.testing.assert_array_equal(e.get_x(), ref.get_x())
 print("TRANSPORT", transport)
@@ -126,3 +132,47 @@ def test_one_rank_communicators(mode, expect):
     out = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}, mode], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "TRANSPORT " + expect in out.stdout
+
+
+@pytest.mark.parametrize("world,batch,tile", [(2, 8, 16), (4, 8, 32), (8, 16, 16), (3, 5, 64)])
+def test_prefetched_row_panels_need_no_per_step_exchange(world, batch, tile):
+    """ekf_prefetch_rows: ONE exchange carries the base row-panels of the next `batch` corrections; each of them then
+    runs without an exchange of its own (ekf_correct on a shard with no communicator would otherwise fail) and the
+    result is bit-identical to the unsharded engine."""
+    from ekf_slam_amd import Engine, EkfError, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 140
+    x, P, s, _, _ = _state(N, 29)
+    g = ShardGroup(world, capacity=N + 4, tile=tile, batch=batch)
+    one = Engine(capacity=N + 4, tile=tile, batch=batch)
+    g.set_state(x, P, s); one.set_state(x, P, s)
+    rng = np.random.default_rng(10)
+    plan = [int(i) for i in rng.integers(0, N, size=3 * batch)]
+    plan[3] = plan[1]                                     # the same landmark twice inside one batch
+    for b0 in range(0, len(plan), batch):
+        chunk = plan[b0:b0 + batch]
+        g.prefetch_rows(sorted(set(chunk)))
+        for idx0 in chunk:
+            u = [0.1, 3.0]
+            z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+            R = np.diag([z[0] * .01, z[1] * 5.0])
+            g.predict(u); one.predict(u)
+            g.correct_local(z, R, idx0); one.correct(z, R, idx0)
+        assert g.shards[0].pending() == one.pending() == 0        # the batch boundary flushed
+    np.testing.assert_array_equal(g.get_x(), one.get_x())
+    np.testing.assert_array_equal(g.get_P(), one.get_P())
+    # after the flush the prefetch is gone: a local correction has nothing to work from
+    with pytest.raises(EkfError) as ei:
+        g.correct_local([5.0, 50.0], np.diag([0.05, 250.0]), plan[0])
+    assert ei.value.status == L.EKF_ERR_STATE
+    # growing the map drops it as well; the per-step exchange still works and stays bit-identical
+    g.prefetch_rows([1, 2, 3])
+    pos = rng.uniform(-5, 5, 2)
+    R = np.diag([0.2, 40.0])
+    g.append([0.1, 3.0], R, pos, N + 1); one.append([0.1, 3.0], R, pos, N + 1)
+    with pytest.raises(EkfError):
+        g.correct_local([5.0, 50.0], R, 2)
+    g.correct([5.0, 50.0], R, 2); one.correct([5.0, 50.0], R, 2)
+    g.correct([6.0, 60.0], R, N); one.correct([6.0, 60.0], R, N)
+    np.testing.assert_array_equal(g.get_P(), one.get_P())
+    g.close(); one.close()
