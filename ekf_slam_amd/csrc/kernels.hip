@@ -953,12 +953,87 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
     return hipGetLastError();
 }
 
+// Batched flush with the G operands staged through LDS (f64 tiles, T = 128, 32-row slabs) -- the production flush.
+// In k_downdate_w every wavefront re-loads its G values pair by pair with vector loads and waits for each of them
+// (L2 latency under full HBM load, 4x redundant across the workgroup's wavefronts).  Here the workgroup copies the
+// G slice of kChunk pairs (kChunk x 128 columns x 16 B) into LDS with one burst of coalesced loads, and the
+// per-pair loop then carries only LDS reads and the scalar K loads -- no vector-memory wait inside it.
+// Measured at 10k landmarks, 32 pairs: 0.77 ms vs 0.91 ms (profiles/round1_tuning.md, sweep 5).
+template <int kChunk>
+__global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles, const int2 *__restrict__ work,
+                                                      int64_t nwork, const double *__restrict__ Kp,
+                                                      const double *__restrict__ Gp, int64_t pair_stride, int npairs,
+                                                      TileMap tm) {
+    constexpr int T = 128, kSlab = 32, kRowsPerWave = 8, kSlabsPerTile = 4;
+    __shared__ double2 Gs[kChunk][T];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nitems = 8 * nwork * kSlabsPerTile;                 // 8 per-XCD streams (see k_downdate_w)
+    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int64_t vi = it >> 3;
+        const int64_t w = vi / kSlabsPerTile;
+        const int slab = (int)(vi - w * kSlabsPerTile);
+        const int2 ij = work[(it & 7) * nwork + w];
+        if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
+        const int row0 = slab * kSlab + wave * kRowsPerWave;
+        double *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)row0 * T + 2 * lane;
+        double2 v[kRowsPerWave];
+#pragma unroll
+        for (int p = 0; p < kRowsPerWave; ++p) v[p] = *reinterpret_cast<const double2 *>(tp + (int64_t)p * T);
+        const int64_t gcol0 = (int64_t)ij.y * T;
+        const int64_t krow = (int64_t)ij.x * T + row0;                // wave-uniform
+        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            __syncthreads();                                          // everyone is done with the previous chunk
+            {
+                constexpr int kPer = kChunk * T / kBlock;             // G values each thread stages per chunk
+                double2 tmp[kPer];
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) {                      // all loads in flight before the first LDS write
+                    const int e = tid + q * kBlock, col = e & (T - 1);
+                    const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;  // clamp: always a valid pair, written only if in range
+                    tmp[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)(c0 + i) * pair_stride)[gcol0 + col];
+                }
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) {
+                    const int e = tid + q * kBlock, i = e >> 7, col = e & (T - 1);
+                    if (i < cn) Gs[i][col] = tmp[q];
+                }
+            }
+            __syncthreads();
+            for (int i = 0; i < cn; ++i) {
+                const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)(c0 + i) * pair_stride) + krow;
+                const double2 ga = Gs[i][2 * lane], gb = Gs[i][2 * lane + 1];
+#pragma unroll
+                for (int p = 0; p < kRowsPerWave; ++p) {
+                    const double2 k = k2[p];                          // uniform address: scalar load
+                    v[p].x = rank2_apply(v[p].x, k, ga);
+                    v[p].y = rank2_apply(v[p].y, k, gb);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kRowsPerWave; ++p) *reinterpret_cast<double2 *>(tp + (int64_t)p * T) = v[p];
+    }
+}
+
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                                      int npairs, int grid_cap, hipStream_t s) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
     if constexpr (kLanes == 64 || kLanes == 32) {
+        static const bool use_lds = [] { const char *v = getenv("EKF_FLUSH_LDS"); return !v || atoi(v) != 0; }();
+        if constexpr (sizeof(TS) == 8 && T == 128 && kSlab == 32) {
+            if (npairs > 1 && use_xcd && use_lds && work_xcd && xcd_len > 0) {
+                int64_t grid = 8 * xcd_len * 4;
+                if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+                hipLaunchKernelGGL((k_flush_lds<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (double *)st.tiles, work_xcd, xcd_len,
+                                   st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+                return hipGetLastError();
+            }
+        }
         if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
             int64_t grid = 8 * xcd_len * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;

@@ -30,21 +30,21 @@ def counter_by_grid(kind, counter, kernel_substr):
     f = glob.glob(os.path.join(src, "pmc_%s" % kind, "*", "*_counter_collection.csv"))[0]
     acc = {}
     for r in csv.DictReader(open(f)):
-        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if any(k in r["Kernel_Name"] for k in kernel_substr) and r["Counter_Name"] == counter:
             acc.setdefault((r["Kernel_Name"], int(r["Grid_Size"])), []).append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
 bench = json.load(open(os.path.join(src, "bench.json")))
-fetch = counter_by_grid("fetch", "FETCH_SIZE", "k_downdate")
-write = counter_by_grid("write", "WRITE_SIZE", "k_downdate")
+fetch = counter_by_grid("fetch", "FETCH_SIZE", ("k_downdate", "k_flush"))
+write = counter_by_grid("write", "WRITE_SIZE", ("k_downdate", "k_flush"))
 legs = []
 for (kname, grid), (f_kib, nf) in sorted(fetch.items(), key=lambda kv: kv[0][1]):
     w_kib, nw = write[(kname, grid)]
     # which leg: the immediate kernel covers 4 rows of a tile per workgroup, the batched flush 32 rows -> 8x fewer workgroups
     immediate = grid == max(g for (_, g) in fetch)
     batch = 1 if immediate else bench["config"]["deferred_batch"]
-    rec = {"kernel": kname.split("(")[0], "grid_size": grid, "landmarks": bench["config"]["landmarks"],
+    rec = {"kernel": "k_flush_lds" if "k_flush_lds" in kname else "k_downdate_w", "grid_size": grid, "landmarks": bench["config"]["landmarks"],
            "tile": bench["config"]["tile"], "batch": batch,
            "FETCH_SIZE_KiB_avg": f_kib, "fetch_dispatches": nf, "WRITE_SIZE_KiB_avg": w_kib, "write_dispatches": nw,
            "hbm_read_bytes_per_launch": 2.0 * f_kib * 1024.0, "hbm_write_bytes_per_launch": w_kib * 1024.0,
