@@ -73,6 +73,12 @@ struct ekf_handle {
     bool have_pp = false;
     PredictArgs pp;
     std::vector<double> s_host;   // host mirror of the signatures (they only change through host calls)
+    // run-ahead throttle: the host may queue at most ~2*kThrottle update-steps ahead of the device.  Measured: the
+    // first time ~150-190 launches are outstanding on a stream, one launch call blocks for 35-45 ms (the runtime
+    // grows a per-queue pool); with the run-ahead bounded below that the stall never happens.
+    hipEvent_t throttle_ev[2] = { nullptr, nullptr };
+    bool throttle_set[2] = { false, false };
+    int throttle_k = 0, since_mark = 0;
     DevState st;
     hipStream_t own_stream = nullptr, stream = nullptr;
     // work list of owned lower-triangle tiles for the active tile rows
@@ -291,10 +297,23 @@ int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
     return cmax * h->T * 2;
 }
 
+constexpr int kThrottle = 48;
+
 int32_t finish_step(ekf_handle *h) {
     h->cur ^= 1;
     h->npend += 1;
-    return h->npend >= h->batch ? flush_pending(h) : EKF_OK;
+    const int32_t rc = h->npend >= h->batch ? flush_pending(h) : EKF_OK;
+    if (rc) return rc;
+    if (++h->since_mark >= kThrottle) {
+        h->since_mark = 0;
+        const int k = h->throttle_k;
+        if (!h->throttle_ev[k]) HIPCHK(h, hipEventCreateWithFlags(&h->throttle_ev[k], hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->throttle_ev[k], h->stream));
+        h->throttle_set[k] = true;
+        if (h->throttle_set[k ^ 1]) HIPCHK(h, hipEventSynchronize(h->throttle_ev[k ^ 1]));   // the mark before this one
+        h->throttle_k = k ^ 1;
+    }
+    return EKF_OK;
 }
 
 void fill_correct_args(ekf_handle *h, CorrectArgs &a, const double z[2], const double R[4], int64_t idx) {
@@ -600,6 +619,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    for (hipEvent_t e : h->throttle_ev) if (e) hipEventDestroy(e);
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);

@@ -1165,3 +1165,4 @@ hipError_t launch_digest(const DevState &st, int cur, int64_t n_mm, const int2 *
         hipLaunchKernelGGL(k_digest<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n_mm, work, nwork, out));
     return hipGetLastError();
 }
+

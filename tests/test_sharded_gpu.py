@@ -122,6 +122,26 @@ for idx0 in (60, 3, 61):
     e.correct(z, R, idx0); ref.correct(z, R, idx0)
 np.testing.assert_array_equal(e.get_P(), ref.get_P())
 np.testing.assert_array_equal(e.get_x(), ref.get_x())
+if mode == "rccl":
+    # a whole scan through ekf_measure: on a sharded handle with a communicator it fetches the scan's row-panels in
+    # one exchange; rows 1..3 correct landmarks 1..3 (known correspondence: idx = row number), row 4 appends
+    obs = np.array([[5.0, 40.0, 1.0], [6.0, 50.0, 2.0], [7.0, 60.0, 3.0], [8.0, 70.0, N + 1.0]])
+    idx = np.arange(1, N + 2, dtype=np.float64); loc = rng.uniform(-20, 20, (N + 1, 2))
+    e2 = Engine(capacity=N + 2, tile=32, batch=4); r2 = Engine(capacity=N + 2, tile=32, batch=4)
+    # e2 was created with EKF_FORCE_SHARDED=0 in the environment -> make a sharded twin explicitly
+    os.environ["EKF_FORCE_SHARDED"] = "1"
+    e3 = Engine(capacity=N + 2, tile=32, batch=4)
+    os.environ["EKF_FORCE_SHARDED"] = "0"
+    raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+    assert L.lib().ekf_comm_unique_id(raw) == 0
+    e3.comm_init(raw.raw)
+    for eng in (e3, r2):
+        eng.set_state(x, P, s)
+        eng.predict([0.1, 3.0])
+        eng.measure(obs, [0.1, 3.0], idx, loc)
+    assert e3.N == r2.N == N + 1
+    np.testing.assert_array_equal(e3.get_x(), r2.get_x())
+    np.testing.assert_array_equal(e3.get_P(), r2.get_P())
 print("TRANSPORT", transport)
 """
 
