@@ -76,6 +76,8 @@ SIGNATURES = {
     "ekf_get_P_block": (_i32, [_vp, _i64, _i64, _i64, _i64, _dp]),
     "ekf_get_Q": (_i32, [_vp, _dp]),
     "ekf_load_lowrank_state": (_i32, [_vp, _i64, _dp, _dp, _dp, _dp, _i64]),
+    "ekf_checkpoint_save": (_i32, [_vp, ctypes.c_char_p]),
+    "ekf_checkpoint_load": (_i32, [_vp, ctypes.c_char_p]),
     "ekf_P_digest": (_i32, [_vp, _dp]),
     "ekf_device_bytes": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "ekf_kernel_timing_enable": (_i32, [_vp, _i32, _i32]),

@@ -1042,6 +1042,109 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     return EKF_OK;
 }
 
+namespace {
+struct CkptHeader {
+    char magic[8];
+    int64_t N;
+    int32_t tile, storage, world, rank;
+    int64_t tile_bytes;      // bytes of the tile section
+    int64_t reserved[3];
+};
+static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
+
+// device -> file / file -> device through a bounded pinned staging buffer
+int32_t stream_out(ekf_handle *h, FILE *f, const void *dev, size_t bytes, void *stage, size_t stage_bytes) {
+    const char *p = (const char *)dev;
+    while (bytes) {
+        const size_t n = bytes < stage_bytes ? bytes : stage_bytes;
+        HIPCHK(h, hipMemcpyAsync(stage, p, n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (fwrite(stage, 1, n, f) != n) return fail(h, EKF_ERR_STATE, "checkpoint: short write");
+        p += n; bytes -= n;
+    }
+    return EKF_OK;
+}
+int32_t stream_in(ekf_handle *h, FILE *f, void *dev, size_t bytes, void *stage, size_t stage_bytes) {
+    char *p = (char *)dev;
+    while (bytes) {
+        const size_t n = bytes < stage_bytes ? bytes : stage_bytes;
+        if (fread(stage, 1, n, f) != n) return fail(h, EKF_ERR_STATE, "checkpoint: short read");
+        HIPCHK(h, hipMemcpyAsync(p, stage, n, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        p += n; bytes -= n;
+    }
+    return EKF_OK;
+}
+}  // namespace
+
+int32_t ekf_checkpoint_save(ekf_handle *h, const char *path) {
+    if (!h || !path) return fail(h, EKF_ERR_INVALID_ARG, "checkpoint_save: null argument");
+    int32_t rc = enter(h);
+    if (rc) return rc;
+    rc = flush_pending(h);
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    REQUIRE(h, f != nullptr, EKF_ERR_STATE, "checkpoint_save: cannot open the file for writing");
+    const size_t stage_bytes = (size_t)32 << 20;
+    void *stage = nullptr;
+    if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { fclose(f); return fail(h, EKF_ERR_HIP, "checkpoint: staging buffer"); }
+    const int64_t nmm = n_mm(h), nt = ekf_tiles_for(nmm, h->T);
+    CkptHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "EKFSLAM1", 8);
+    hd.N = h->N; hd.tile = h->T; hd.storage = h->storage; hd.world = h->cfg.world; hd.rank = h->cfg.rank;
+    hd.tile_bytes = h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h);
+    rc = fwrite(&hd, sizeof hd, 1, f) == 1 ? EKF_OK : fail(h, EKF_ERR_STATE, "checkpoint: short write");
+    if (!rc) rc = stream_out(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
+    if (!rc && h->N > 0) rc = stream_out(h, f, h->st.s, (size_t)h->N * 8, stage, stage_bytes);
+    if (!rc) rc = stream_out(h, f, h->st.prr[h->cur], 9 * 8, stage, stage_bytes);
+    for (int r = 0; r < 3 && !rc && nmm > 0; ++r)
+        rc = stream_out(h, f, h->st.strip[h->cur] + (size_t)r * h->st.ldm, (size_t)nmm * 8, stage, stage_bytes);
+    if (!rc && hd.tile_bytes > 0) rc = stream_out(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
+    hipHostFree(stage);
+    if (fclose(f) != 0 && !rc) rc = fail(h, EKF_ERR_STATE, "checkpoint: close failed");
+    return rc;
+}
+
+int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
+    if (!h || !path) return fail(h, EKF_ERR_INVALID_ARG, "checkpoint_load: null argument");
+    int32_t rc = enter(h);
+    if (rc) return rc;
+    FILE *f = fopen(path, "rb");
+    REQUIRE(h, f != nullptr, EKF_ERR_STATE, "checkpoint_load: cannot open the file");
+    CkptHeader hd;
+    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM1", 8) != 0) { fclose(f); return fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM1 file"); }
+    if (hd.tile != h->T || hd.storage != h->storage || hd.world != h->cfg.world || hd.rank != h->cfg.rank || hd.N < 0 || hd.N > h->cap) {
+        fclose(f);
+        return fail(h, EKF_ERR_STATE, "checkpoint_load: tile edge, storage, shard or capacity do not match this handle");
+    }
+    const int64_t nmm = 2 * hd.N, nt = ekf_tiles_for(nmm, h->T);
+    if (hd.tile_bytes != h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h)) { fclose(f); return fail(h, EKF_ERR_STATE, "checkpoint_load: tile section size mismatch"); }
+    const size_t stage_bytes = (size_t)32 << 20;
+    void *stage = nullptr;
+    if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { fclose(f); return fail(h, EKF_ERR_HIP, "checkpoint: staging buffer"); }
+    h->npend = 0; h->pf_valid = false; h->have_pp = false;
+    HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+    std::vector<double> shost((size_t)hd.N);
+    rc = stream_in(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
+    if (!rc && hd.N > 0) {
+        const long at = ftell(f);
+        rc = stream_in(h, f, h->st.s, (size_t)hd.N * 8, stage, stage_bytes);
+        if (!rc) { fseek(f, at, SEEK_SET); if (fread(shost.data(), 8, (size_t)hd.N, f) != (size_t)hd.N) rc = fail(h, EKF_ERR_STATE, "checkpoint: short read"); }
+    }
+    if (!rc) rc = stream_in(h, f, h->st.prr[h->cur], 9 * 8, stage, stage_bytes);
+    for (int r = 0; r < 3 && !rc && nmm > 0; ++r)
+        rc = stream_in(h, f, h->st.strip[h->cur] + (size_t)r * h->st.ldm, (size_t)nmm * 8, stage, stage_bytes);
+    if (!rc && hd.tile_bytes > 0) rc = stream_in(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
+    hipHostFree(stage);
+    fclose(f);
+    if (rc) return rc;
+    h->N = hd.N;
+    h->s_host = shost;
+    return EKF_OK;
+}
+
 int32_t ekf_P_digest(ekf_handle *h, double out[3]) {
     if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "P_digest: null argument");
     int32_t rc = enter(h);

@@ -80,7 +80,9 @@ __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, i
 // bit-identical results.  in: pose[3], M = Prr (row-major); out: fa = F(1,3), fb = F(2,3), new pose, Prr' , Q.
 struct PredictSmall { double fa, fb; double pose[3]; double prr[9]; double Q[9]; };
 
-__device__ inline void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
+// noinline: ONE machine-code body shared by every kernel that needs it, so that the standalone predict and the predict
+// folded into a correction cannot differ by a rounding (inlined copies did: different libm expansion per context)
+__device__ __attribute__((noinline)) void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
                                      PredictSmall &o) {
     const double th = pose[2];
     // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
@@ -254,7 +256,7 @@ struct SmallSolve {
 };
 
 // pss: 0..8 Prr row-major; 9+2t+b = P(t, j+b), t<3, b<2; 15+2t+b = canonical P(j+t, j+b); 19..21 x_r; 22..23 x_j
-__device__ inline void solve_small(const double *pss, double z0, double z1, double R00, double R01, double R10,
+__device__ __attribute__((noinline)) void solve_small(const double *pss, double z0, double z1, double R00, double R01, double R10,
                                    double R11, SmallSolve &o) {
     const double d0 = pss[22] - pss[19], d1 = pss[23] - pss[20];                       // EKF_SLAM.m:125-126
     const double q = d0 * d0 + d1 * d1, sq = sqrt(q);                                  // :127

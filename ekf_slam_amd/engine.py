@@ -216,6 +216,12 @@ class Engine:
         self._check(self.lib.ekf_load_lowrank_state(self.h, N, _p(x), _p(s) if s.size else _p(np.zeros(1)), _p(d),
                                                     _p(U.reshape(-1, order="F")), U.shape[1]))
 
+    def checkpoint_save(self, path):
+        self._check(self.lib.ekf_checkpoint_save(self.h, str(path).encode()))
+
+    def checkpoint_load(self, path):
+        self._check(self.lib.ekf_checkpoint_load(self.h, str(path).encode()))
+
     def digest(self):
         out = np.empty(3)
         self._check(self.lib.ekf_P_digest(self.h, _p(out)))

@@ -38,6 +38,7 @@ class _EkfBase:
         self._e = Engine(mode=self._mode, capacity=capacity, **engine_kw)
         self.landmark_list = None
         self.observed = None
+        self.log = None             # a TrajectoryLog records what predict / measure consume
 
     # ---- the reference's public properties, pulled from HBM on demand ----
     @property
@@ -86,6 +87,7 @@ class _EkfBase:
 
     # ---- methods ----
     def predict(self, u):
+        self._last_u = np.asarray(u, dtype=np.float64)
         self._e.predict(u)
 
     def f(self, x, u):
@@ -104,9 +106,11 @@ class _EkfBase:
     def measure(self, laserData, u, landmark_list):
         observed_LL = landmark_list.getLandmark(laserData, self.x)       # EKF_SLAM.m:102
         self.observed = observed_LL                                      # :103
+        idx, loc = landmark_list.landmarkObj.table()
+        if self.log is not None:
+            self.log.record(u, observed_LL, idx, loc)
         if observed_LL is None or len(observed_LL) == 0:                 # :105
             return
-        idx, loc = landmark_list.landmarkObj.table()
         self._e.measure(observed_LL, u, idx, loc)
 
     def plot_data(self):
