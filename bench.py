@@ -204,7 +204,11 @@ def main():
             dt = float(t.item())
         x_end = e.get_x()
         finite = bool(np.isfinite(x_end).all())
-        digest = e.digest()
+        digest = e.digest()                      # this rank's tiles (+ the replicated robot rows on rank 0)
+        if dist is not None:
+            tdig = torch.tensor(digest, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tdig, op=dist.ReduceOp.SUM)
+            digest = tdig.cpu().numpy()
         e.close()
         avg_ms = kernel_ms / max(launches, 1)
         achieved = b_alg_rank / (avg_ms * 1e-3)
@@ -245,7 +249,10 @@ def main():
                        "landmarks": N, "state_dim": n, "tile": args.tile, "storage": "f64",
                        "deferred_batch": args.batch,
                        "shard": "tile (I,J) on rank (I+J) mod %d" % world, "transport": head["transport"],
-                       "state_finite": head["state_finite"]},
+                       "state_finite": head["state_finite"],
+                       # trace / sum / sum of squares of the final P (lower triangle): the same workload gives the same
+                       # digest on 1, 2, 4 or 8 GPUs and in deferred or immediate mode (to summation order)
+                       "state_digest": [float(v) for v in head["digest"]]},
             "roofline": head["roofline"],
         }
         if look is not None:

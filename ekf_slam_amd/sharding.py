@@ -65,21 +65,24 @@ def attach_communicator(engine, dist, torch, prefer="rccl"):
     send = torch.zeros(cap, dtype=torch.float64, device="cuda")
     recv = torch.zeros(cap * world, dtype=torch.float64, device="cuda")
     engine.exchange_set_buffers(send.data_ptr(), recv.data_ptr())
-    engine.set_stream(torch.cuda.current_stream().cuda_stream)
-    engine._xchg_tensors = (send, recv)
-
+    # The engine must launch on the stream the collective is ordered with.  torch's default stream is the NULL stream,
+    # which ekf_set_stream reads as "use your own stream" -- so run everything on a dedicated torch stream.
+    xstream = torch.cuda.Stream()
+    engine.set_stream(xstream.cuda_stream)
+    engine._xchg_tensors = (send, recv, xstream)
     staged = dist.get_backend() != "nccl"      # e.g. gloo (rehearsals on one GPU): stage through host memory
 
     def host_exchange(e):
         _, _, cnt, _ = e.exchange_info()
-        if staged:
-            torch.cuda.current_stream().synchronize()
-            s_cpu = send[:cnt].cpu()
-            parts = [torch.empty_like(s_cpu) for _ in range(world)]
-            dist.all_gather(parts, s_cpu)
-            recv[:cnt * world].copy_(torch.cat(parts))
-        else:
-            dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
+        with torch.cuda.stream(xstream):
+            if staged:
+                xstream.synchronize()
+                s_cpu = send[:cnt].cpu()
+                parts = [torch.empty_like(s_cpu) for _ in range(world)]
+                dist.all_gather(parts, s_cpu)
+                recv[:cnt * world].copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
 
     engine._host_exchange = host_exchange
     return "torch.distributed" if not staged else "torch.distributed(%s, host-staged)" % dist.get_backend()
