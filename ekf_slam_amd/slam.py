@@ -166,14 +166,19 @@ class Correspondence:
 
 
 class Landmark:
-    """Landmark.m surface.  'SYNTHETIC' is the seeded source of ekf_slam_amd.world; 'RANSAC' (Landmark.m:14-16)
-    needs a live ROS laser scan and MATLAB toolboxes and is out of scope."""
+    """Landmark.m surface.  'SYNTHETIC' is the seeded source of ekf_slam_amd.world; 'RANSAC' (Landmark.m:14-16) is the
+    reference's landmark-list bookkeeping (ekf_slam_amd.ransac_bookkeeping) fed with wall foot-points -- the laser-scan
+    line extraction itself needs ROS and MATLAB toolboxes and is out of scope."""
 
     def __init__(self, method):
         self.method = method
         if method == 'SYNTHETIC':
             self._src = SyntheticLandmark(method)
             self.landmarkObj = self._src.landmarkObj
+        elif method == 'RANSAC':
+            from .ransac_bookkeeping import RansacBookkeeping
+            self.landmarkObj = RansacBookkeeping()
+            self._src = self.landmarkObj
         else:
             warnings.warn('Improper landmark recognition method.')       # Landmark.m:18
             self._src = SyntheticLandmark('SYNTHETIC')
@@ -201,7 +206,7 @@ def append(x, P, u, idx, R, pos, **engine_kw):
 class SLAM:
     """SLAM.m facade with the ROS subscribers replaced by a scripted feed of (u, scan) pairs."""
 
-    def __init__(self, inputString, feed=None, capacity=_DEFAULT_CAPACITY, **engine_kw):
+    def __init__(self, inputString, feed=None, capacity=_DEFAULT_CAPACITY, landmark_method='SYNTHETIC', **engine_kw):
         self.algorithmName = inputString
         self.feed = iter(feed) if feed is not None else None
         self.u = np.zeros(3)
@@ -211,7 +216,7 @@ class SLAM:
             self.slam = EKF_SLAM_UC(capacity, **engine_kw)
         else:
             self.slam = None
-        self.LM = Landmark('SYNTHETIC')
+        self.LM = Landmark(landmark_method)       # SLAM.m:29,34 use 'RANSAC'
 
     def predict(self, u):
         if self.slam is not None:

@@ -59,3 +59,35 @@ def test_class_surface_matches_reference_names():
     assert len(x2) == 15 and P2.shape == (15, 15)
     x3, _ = slam.append(x, P, [0.1, 3.0], 5, np.diag([0.2, 150.0]), [1.0, 2.0])
     assert len(x3) == 13
+
+
+def test_runslam_end_to_end_with_ransac_bookkeeping():
+    """SLAM('EKF_SLAM') with Landmark('RANSAC'): the reference's landmark-list bookkeeping (consensus counts, index
+    assignment, single observed row) fed with synthetic wall foot-points, against the literal-dense oracle driven by
+    its own copy of the same bookkeeping."""
+    from ekf_slam_amd import slam
+    from ekf_slam_amd.ransac_bookkeeping import RansacBookkeeping
+    from oracle import ekf_dense as D
+
+    rng = np.random.default_rng(8)
+    walls = np.array([[2.0, 1.0], [-1.5, 2.5]])
+    feed = []
+    for t in range(45):
+        u = [0.05 + 0.001 * t, 2.0]
+        pts = walls[:1 if t < 20 else 2] + rng.normal(0, 0.01, (1 if t < 20 else 2, 2))
+        feed.append((u, pts))
+    s = slam.SLAM('EKF_SLAM', feed=feed, capacity=8, tile=16, landmark_method='RANSAC')
+
+    class _LM:                       # Landmark.m shape around the oracle's own bookkeeping object
+        def __init__(self):
+            self.landmarkObj = RansacBookkeeping()
+
+        def getLandmark(self, laser, x):
+            return self.landmarkObj.getLandmark(laser, x)
+    ref, lm = D.EKF_SLAM(), _LM()
+    for u, pts in feed:
+        s.runSlam()
+        ref.predict(u); ref.measure(pts, u, lm)
+    assert s.slam._e.N == (len(ref.x) - 3) // 2 >= 1
+    assert rel_err(s.slam.x, ref.x) < REL and rel_err(s.slam.P, ref.P) < REL
+    assert [e.index for e in s.LM.landmarkObj.landmark] == [e.index for e in lm.landmarkObj.landmark]
