@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--async-flush", action="store_true",
+                    help="run each pass over P on a second stream into a second tile store (measured: no gain, see "
+                         "profiles/round1_tuning.md sweep 6)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-immediate", action="store_true")
     args = ap.parse_args()
@@ -157,7 +160,8 @@ def main():
     conditioned = [False]
 
     def run_leg(batch, nsteps, nwarm, lookahead=False):
-        e = Engine(mode="known", capacity=N, tile=args.tile, device=device, rank=rank, world=world, batch=batch)
+        e = Engine(mode="known", capacity=N, tile=args.tile, device=device, rank=rank, world=world, batch=batch,
+                   async_flush=(batch > 1 and args.async_flush))
         e.load_lowrank_state(x, s, d, U)
         transport = "none"
         if world > 1:
@@ -247,7 +251,7 @@ def main():
             "config": {"workload": "configs[2]: %d landmarks, known correspondence (EKF_SLAM.m), F64; step = 1 predict"
                                    " + 1 correction on a cycling landmark; P split over %d GPU(s)" % (N, world),
                        "landmarks": N, "state_dim": n, "tile": args.tile, "storage": "f64",
-                       "deferred_batch": args.batch,
+                       "deferred_batch": args.batch, "async_flush": bool(args.batch > 1 and args.async_flush),
                        "shard": "tile (I,J) on rank (I+J) mod %d" % world, "transport": head["transport"],
                        "state_finite": head["state_finite"],
                        # trace / sum / sum of squares of the final P (lower triangle): the same workload gives the same

@@ -66,8 +66,20 @@ struct ekf_handle {
     int32_t T = 64;
     int32_t storage = 0;
     int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
-    int32_t batch = 1;     // max pending rank-2 pairs
-    int32_t npend = 0;     // pending pairs (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
+    int32_t batch = 1;     // corrections per pass over P
+    int32_t npend = 0;     // pending pairs a reader must apply (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
+    int32_t pstart = 0;    // ring slot of the oldest pending pair
+    // Asynchronous flush (cfg.batch > 1, f64/f32 alike): the pass over P runs on a second stream from the current
+    // tile store into the OTHER one while the next corrections keep reading the current store plus all pending
+    // pairs (those being flushed, `nfrozen`, and the ones recorded since).  At the next batch boundary the stores
+    // swap.  Readers of P, appends and state loads first retire the in-flight flush.
+    bool async_flush = false;
+    void *tilebuf[2] = { nullptr, nullptr };
+    int32_t base = 0;          // tilebuf[base] == st.tiles: the store kernels read
+    int32_t nfrozen = 0;       // pending pairs that belong to the in-flight flush (the oldest ones)
+    bool inflight = false;
+    hipStream_t flush_stream = nullptr;
+    hipEvent_t ev_pairs = nullptr, ev_flushed = nullptr;
     // lazy predict: ekf_predict only records u; the next correction folds it into its gather kernel (one launch
     // instead of two, identical arithmetic); any other consumer of x / P launches k_predict first
     bool have_pp = false;
@@ -227,18 +239,69 @@ void colmajor2(const double R[4], double &r00, double &r01, double &r10, double 
     r00 = R[0]; r10 = R[1]; r01 = R[2]; r11 = R[3];
 }
 
-// apply the pending pairs to the tiles: ONE pass over P for npend update-steps
+// The in-flight asynchronous flush becomes visible: later kernels on the main stream wait for it, the stores swap,
+// its pairs leave the pending list.
+int32_t retire_inflight(ekf_handle *h) {
+    if (!h->inflight) return EKF_OK;
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_flushed, 0));
+    h->base ^= 1;
+    h->st.tiles = h->tilebuf[h->base];
+    h->pstart = (h->pstart + h->nfrozen) % h->st.pcap;
+    h->npend -= h->nfrozen;
+    h->nfrozen = 0;
+    h->inflight = false;
+    h->pf_valid = false;       // prefetched row-panels were base values of the old store
+    return EKF_OK;
+}
+
+// apply ALL pending pairs to the tiles now, in place on the main stream: ONE pass over P for npend update-steps
 int32_t flush_pending(ekf_handle *h) {
+    int32_t rc = retire_inflight(h);
+    if (rc) return rc;
     if (h->npend == 0) return EKF_OK;
-    int32_t rc = refresh_work(h);
+    rc = refresh_work(h);
     if (rc) return rc;
     {
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
-        HIPCHK(h, launch_downdate(h->st, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->npend, h->storage, h->grid_cap,
-                                  h->stream));
+        HIPCHK(h, launch_downdate(h->st, h->st.tiles, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart, h->npend,
+                                  h->storage, h->grid_cap, h->stream));
     }
     h->npend = 0;
+    h->pstart = 0;
     h->pf_valid = false;       // the prefetched row-panels were base values of the old tiles
+    return EKF_OK;
+}
+
+// a batch is complete: start its pass over P.  Synchronous engines do it in place; asynchronous ones launch it on the
+// flush stream into the other tile store and keep going.
+int32_t batch_complete(ekf_handle *h) {
+    if (!h->async_flush) return flush_pending(h);
+    int32_t rc = retire_inflight(h);              // at most one flush in flight: the previous one must be done first
+    if (rc) return rc;
+    rc = refresh_work(h);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_pairs, h->stream));                     // every pair of the batch has been written,
+    HIPCHK(h, hipStreamWaitEvent(h->flush_stream, h->ev_pairs, 0));        // every reader of the other store is queued before
+    {
+        KernelTimer *t = &h->timers[EKF_KERNEL_DOWNDATE];
+        hipEvent_t stop = nullptr;
+        if (t->enabled) {
+            if (t->used + 2 > t->ev.size()) {
+                hipEvent_t a, b;
+                HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+                t->ev.push_back(a); t->ev.push_back(b);
+            }
+            HIPCHK(h, hipEventRecord(t->ev[t->used], h->flush_stream));
+            stop = t->ev[t->used + 1];
+            t->used += 2;
+        }
+        HIPCHK(h, launch_downdate(h->st, h->tilebuf[h->base ^ 1], h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart,
+                                  h->npend, h->storage, h->grid_cap, h->flush_stream));
+        if (stop) HIPCHK(h, hipEventRecord(stop, h->flush_stream));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_flushed, h->flush_stream));
+    h->nfrozen = h->npend;
+    h->inflight = true;
     return EKF_OK;
 }
 
@@ -273,7 +336,9 @@ int32_t enter(ekf_handle *h) {
 int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature) {
     REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
     {
-        const int32_t rcp = materialize_predict(h);
+        int32_t rcp = materialize_predict(h);
+        if (rcp) return rcp;
+        rcp = retire_inflight(h);          // the new rows must land in the store every later kernel reads
         if (rcp) return rcp;
     }
     AppendArgs a;
@@ -302,7 +367,7 @@ constexpr int kThrottle = 48;
 int32_t finish_step(ekf_handle *h) {
     h->cur ^= 1;
     h->npend += 1;
-    const int32_t rc = h->npend >= h->batch ? flush_pending(h) : EKF_OK;
+    const int32_t rc = (h->npend - h->nfrozen) >= h->batch ? batch_complete(h) : EKF_OK;
     if (rc) return rc;
     if (++h->since_mark >= kThrottle) {
         h->since_mark = 0;
@@ -319,7 +384,7 @@ int32_t finish_step(ekf_handle *h) {
 void fill_correct_args(ekf_handle *h, CorrectArgs &a, const double z[2], const double R[4], int64_t idx) {
     a.z0 = z[0]; a.z1 = z[1];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend;
+    a.j = 2 * idx; a.n_mm = n_mm(h); a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
 }
 
 // slot of landmark idx among the prefetched base row-panels, or -1
@@ -336,7 +401,8 @@ int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64
     if (rc) return rc;
     fill_correct_args(h, h->pending_args, z, R, idx);
     h->slab = slab_for(h, h->pending_args.n_mm);
-    HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->npend, h->send, h->storage, h->stream));
+    HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->pstart, h->npend, h->send, h->storage,
+                              h->stream));
     h->pending = true; h->pending_kind = 1; h->x_count = h->slab;
     return EKF_OK;
 }
@@ -363,7 +429,7 @@ int32_t prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
         REQUIRE(h, idx[q] >= 0 && idx[q] < h->N, EKF_ERR_INDEX, "prefetch: landmark index outside the state");
     const int64_t slab = slab_for(h, n_mm(h));
     for (int32_t q = 0; q < m; ++q)
-        HIPCHK(h, launch_rowpanel(h->st, 2 * idx[q], n_mm(h), /*npend*/ 0, h->send + (size_t)q * slab, h->storage, h->stream));
+        HIPCHK(h, launch_rowpanel(h->st, 2 * idx[q], n_mm(h), 0, /*npend*/ 0, h->send + (size_t)q * slab, h->storage, h->stream));
     h->pf_valid = false;
     h->pf_idx.assign(idx, idx + m);
     h->pf_m = m; h->pf_slab = slab; h->pf_N = h->N;
@@ -440,7 +506,7 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
     a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
-    a.N = h->N; a.cur = h->cur; a.npend = h->npend;
+    a.N = h->N; a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
     {
         TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
         HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_decision, h->storage,
@@ -526,6 +592,7 @@ int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
     cfg->rank = 0;
     cfg->world = 1;
     cfg->batch = 1;
+    cfg->async_flush = 0;
     return EKF_OK;
 }
 
@@ -554,7 +621,13 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     *out = h;   // returned even on failure so the caller can read ekf_last_error, then ekf_destroy
 
     HIPCHK(h, hipSetDevice(cfg->device));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    {
+        // the main stream carries the latency-bound step kernels: highest priority, so that their few workgroups are
+        // dispatched ahead of the tens of thousands a concurrent flush (own stream, lowest priority) has queued
+        int lo = 0, hi = 0;
+        HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(h, hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, hi));
+    }
     h->stream = h->own_stream;
 
     const int64_t nt_cap = ekf_tiles_for(2 * h->cap, T);
@@ -572,13 +645,28 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         char *tiles = nullptr;
         HIPCHK(h, dalloc(h, &tiles, (size_t)slots * T * T * elt_size(h)));
         h->st.tiles = tiles;
+        h->tilebuf[0] = tiles;
+        h->async_flush = cfg->async_flush != 0 && cfg->batch > 1;
+        if (h->async_flush) {
+            char *tiles2 = nullptr;
+            HIPCHK(h, dalloc(h, &tiles2, (size_t)slots * T * T * elt_size(h)));
+            h->tilebuf[1] = tiles2;
+            {
+                int lo = 0, hi = 0;
+                HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(h, hipStreamCreateWithPriority(&h->flush_stream, hipStreamNonBlocking, lo));
+            }
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_pairs, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_flushed, hipEventDisableTiming));
+        }
     }
     HIPCHK(h, dalloc(h, &h->st.s, (size_t)h->cap));
     h->batch = cfg->batch < 1 ? 1 : cfg->batch;
     h->cfg.batch = h->batch;
     h->st.pair_stride = 2 * ldm;
-    HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->batch));
-    HIPCHK(h, dalloc(h, &h->st.Kp, (size_t)(2 * ldm) * h->batch));
+    h->st.pcap = h->async_flush ? 2 * h->batch : h->batch;      // in-flight batch + the batch being recorded
+    HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap));
+    HIPCHK(h, dalloc(h, &h->st.Kp, (size_t)(2 * ldm) * h->st.pcap));
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
     HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));
@@ -620,6 +708,9 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (hipEvent_t e : h->throttle_ev) if (e) hipEventDestroy(e);
+    if (h->flush_stream) { hipStreamSynchronize(h->flush_stream); hipStreamDestroy(h->flush_stream); }
+    if (h->ev_pairs) hipEventDestroy(h->ev_pairs);
+    if (h->ev_flushed) hipEventDestroy(h->ev_flushed);
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);
@@ -645,6 +736,7 @@ int32_t ekf_sync(ekf_handle *h) {
     int32_t rc = enter(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->flush_stream) HIPCHK(h, hipStreamSynchronize(h->flush_stream));
     return EKF_OK;
 }
 
@@ -919,8 +1011,8 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     rc = flush_pending(h);     // pending pairs belong to the old state
     if (rc) return rc;
     if ((n - 3) / 2 < h->N) {  // shrinking the map: pair slots must read as zero beyond the active columns
-        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
     }
     h->N = (n - 3) / 2;
     h->s_host.resize((size_t)h->N, 0.0);
@@ -971,7 +1063,8 @@ int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
     REQUIRE(h, n == 3 + n_mm(h), EKF_ERR_INVALID_ARG, "set_P: n must equal length(x) (set x first)");
     int32_t rc = enter(h);
     if (rc) return rc;
-    h->npend = 0;              // the whole covariance is replaced
+    { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
+    h->npend = 0; h->pstart = 0;   // the whole covariance is replaced
     double *dense = nullptr;
     HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
     hipError_t e = hipMemcpyAsync(dense, P, (size_t)(n * n) * 8, hipMemcpyHostToDevice, h->stream);
@@ -1019,12 +1112,13 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     if (rc) return rc;
     const int64_t n = 3 + 2 * N;
     if (N < h->N) {
-        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
     }
     h->N = N;
     h->s_host.assign(s, s + N);
-    h->npend = 0;              // the whole state is replaced
+    { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
+    h->npend = 0; h->pstart = 0;   // the whole state is replaced
     rc = refresh_work(h);
     if (rc) return rc;
     double *dd = nullptr, *dU = nullptr;
@@ -1123,9 +1217,10 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     const size_t stage_bytes = (size_t)32 << 20;
     void *stage = nullptr;
     if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { fclose(f); return fail(h, EKF_ERR_HIP, "checkpoint: staging buffer"); }
-    h->npend = 0; h->pf_valid = false; h->have_pp = false;
-    HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->batch * 8, h->stream));
+    { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
+    h->npend = 0; h->pstart = 0; h->pf_valid = false; h->have_pp = false;
+    HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
     std::vector<double> shost((size_t)hd.N);
     rc = stream_in(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
     if (!rc && hd.N > 0) {
@@ -1191,6 +1286,7 @@ int32_t ekf_kernel_timing_read(ekf_handle *h, int32_t which, int64_t *launches, 
     int32_t rc = use_device(h);
     if (rc) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->flush_stream) HIPCHK(h, hipStreamSynchronize(h->flush_stream));
     KernelTimer &t = h->timers[which];
     double tot = 0.0;
     for (size_t i = 0; i + 1 < t.used; i += 2) {

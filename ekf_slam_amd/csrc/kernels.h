@@ -17,9 +17,12 @@ struct DevState {
     // Pending rank-2 pairs: slot i holds G_i = H_s P(S,:) over landmark columns, interleaved (G(1,c), G(2,c)),
     // and K_i over landmark rows, interleaved (K(r,1), K(r,2)); slots are pair_stride doubles apart.  The tiles
     // hold P_base; the live landmark block is P_base - sum_i K_i G_i (applied in slot order).
+    // The slots form a ring of `pcap` entries: a kernel that is told (pstart, npend) sees the pairs in slots
+    // (pstart + i) mod pcap, i = 0 .. npend-1, oldest first.
     double *Gp;
     double *Kp;
     int64_t pair_stride;   // 2 * ldm
+    int32_t pcap;          // slots in the ring
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
     int64_t ldm;       // strip leading dimension = landmark-block capacity rounded up to T
     TileMap tm;
@@ -31,7 +34,8 @@ struct CorrectArgs {
     int64_t j;                // landmark-block row of the corrected landmark (2*idx)
     int64_t n_mm;             // active landmark-block size (2N)
     int32_t cur;
-    int32_t npend;            // pending pairs before this correction; its own pair goes to slot npend
+    int32_t npend;            // pending pairs before this correction; its own pair goes to ring position npend
+    int32_t pstart;           // ring slot of the oldest pending pair
 };
 
 struct PredictArgs {
@@ -55,6 +59,7 @@ struct AssocArgs {
     int64_t N;
     int32_t cur;
     int32_t npend;
+    int32_t pstart;
 };
 
 struct AssocDecision {        // written by the device, read back by the host
@@ -75,7 +80,8 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
 int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
-hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s);
+hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
+                           hipStream_t s);
 // recv: `world` contributions `rank_stride` doubles apart; this correction's row-panel starts `offset` doubles into
 // each; patched: the pending pairs are already applied to it (k_rowpanel) -- otherwise the gather applies them
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
@@ -84,8 +90,10 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // lower-triangle tiles: ONE pass over P for npairs update-steps
 // work_xcd / xcd_len: the same tiles as 8 per-XCD streams (stream x = work_xcd[x*xcd_len ..), padded with (-1,-1)),
 // used when several pairs are applied so that each XCD's K/G working set stays inside its own L2
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int npairs, int storage, int grid_cap, hipStream_t s);
+// dst: tile store the result is written to (== st.tiles for an in-place flush; a second buffer for the asynchronous
+// flush, which must not disturb kernels still reading st.tiles); pstart: ring slot of the first pair
+hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s);

@@ -48,14 +48,17 @@ __device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
     return fma(-k.y, g.y, fma(-k.x, g.x, v));       // v - K(r,1) G(1,c) - K(r,2) G(2,c): two FMAs, fixed order
 }
 
+__device__ __forceinline__ int ring_slot(int pstart, int i, int pcap) { const int s = pstart + i; return s >= pcap ? s - pcap : s; }
+
 // live value of canonical element (r >= c enforced here) = base - sum over pending pairs, in slot order
 template <typename TS>
-__device__ __forceinline__ double pmm_live(const TS *__restrict__ tiles, const DevState &st, int npend, int64_t r, int64_t c) {
+__device__ __forceinline__ double pmm_live(const TS *__restrict__ tiles, const DevState &st, int pstart, int npend, int64_t r, int64_t c) {
     if (r < c) { const int64_t t = r; r = c; c = t; }
     double v = pmm_low<TS>(tiles, st.tm, r, c);
     for (int i = 0; i < npend; ++i) {
-        const double2 k = reinterpret_cast<const double2 *>(st.Kp + (int64_t)i * st.pair_stride)[r];
-        const double2 g = reinterpret_cast<const double2 *>(st.Gp + (int64_t)i * st.pair_stride)[c];
+        const int64_t so = (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
+        const double2 k = reinterpret_cast<const double2 *>(st.Kp + so)[r];
+        const double2 g = reinterpret_cast<const double2 *>(st.Gp + so)[c];
         v = rank2_apply(v, k, g);
     }
     return v;
@@ -309,19 +312,19 @@ struct PanelView {
     }
 };
 
-constexpr int kMaxPending = 64;        // cfg.batch upper bound (LDS staging of the wave-uniform patch operands)
+constexpr int kMaxPending = 128;       // 2 * max cfg.batch: pairs of an in-flight flush + pairs recorded since (LDS staging bound)
 
 // Each shard copies the chunks of M it owns (canonical lower-triangle entries, patched with the pending pairs in
 // slot order exactly like the unsharded gather does) into its send slab.
 template <typename TS>
-__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int npend,
+__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int pstart, int npend,
                                                      double *__restrict__ send, int64_t nchunks_local) {
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const TileMap &tm = st.tm;
     const TS *__restrict__ tiles = (const TS *)st.tiles;
     for (int e = threadIdx.x; e < 4 * npend; e += kBlock) {
         const int i = e >> 2, which = e & 3;
-        const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)i * st.pair_stride;
+        const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
         upatch[e] = reinterpret_cast<const double2 *>(base)[j + (which & 1)];
     }
     __syncthreads();
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
             m1 = pmm_low<TS>(tiles, tm, j + 1, c);
             const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
             for (int i = 0; i < npend; ++i) {
-                const double2 g = gp[(int64_t)i * ps2];
+                const double2 g = gp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
                 m0 = rank2_apply(m0, upatch[4 * i + 0], g);
                 m1 = rank2_apply(m1, upatch[4 * i + 1], g);
             }
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
             m1 = pmm_low<TS>(tiles, tm, c, j + 1);
             const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
             for (int i = 0; i < npend; ++i) {
-                const double2 k = kp[(int64_t)i * ps2];
+                const double2 k = kp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
                 m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
                 m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
             }
@@ -377,10 +380,26 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     const double *__restrict__ strip = st.strip[cur];
     const TS *__restrict__ tiles = (const TS *)st.tiles;
     const int64_t j = a.j, ldm = st.ldm;
-    const int npend = a.npend;
+    const int npend = a.npend, pstart = a.pstart;
 
     const bool do_patch = !kSharded || !pv.patched;       // base values in hand: apply the pending pairs here
+    const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
+    const bool live = c < a.n_mm;
 
+    // (1) everything this column needs from memory is requested FIRST, so that it arrives while lane 0 runs the scalar
+    //     prologue below: the two landmark rows at column c (canonical lower-triangle entries: row part left of j,
+    //     column part right of j+1; from the tiles or from the exchanged row-panel), the strip column, x(c)
+    double m0 = 0.0, m1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, xc = 0.0;
+    if (live) {
+        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
+        else if (c <= j) { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
+        else if (c >= j + 2) { m0 = pmm_low<TS>(tiles, st.tm, c, j); m1 = pmm_low<TS>(tiles, st.tm, c, j + 1); }
+        else { m0 = pmm_low<TS>(tiles, st.tm, j + 1, j); m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1); }   // c == j + 1
+        s0 = strip[c]; s1 = strip[ldm + c]; s2 = strip[2 * ldm + c];
+        xc = x[3 + c];
+    }
+
+    // (2) the 5x5 sub-block P(S,S), the pose and the landmark, plus the wave-uniform operands of the pending pairs
     if (tid < 9) pss[tid] = st.prr[cur][tid];
     else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
     else if (tid < 19) {
@@ -397,14 +416,17 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     if (do_patch) {
         for (int e = tid; e < 4 * npend; e += kBlock) {
             const int i = e >> 2, which = e & 3;
-            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)i * st.pair_stride;
+            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
             upatch[e] = reinterpret_cast<const double2 *>(base)[j + (which & 1)];
         }
     }
     __syncthreads();
+
+    // (3) lane 0: live 2x2 diagonal block, optional predict, the 2x2 solve.  Every other lane meanwhile applies the
+    //     pending pairs to its two row entries (none of that depends on the solve).
     if (tid == 0) {
         if (do_patch) {
-            // live 2x2 diagonal block: canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
+            // canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
             double d00 = pss[15], d10 = pss[17], d11 = pss[18];
             for (int i = 0; i < npend; ++i) {
                 d00 = rank2_apply(d00, upatch[4 * i + 0], upatch[4 * i + 2]);
@@ -423,68 +445,60 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         }
         solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
     }
-    __syncthreads();
-
-    const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
-    const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
-    double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + (int64_t)npend * st.pair_stride);
-    double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + (int64_t)npend * st.pair_stride);
-    if (c < a.n_mm) {
-        // the two landmark rows at column c: canonical lower-triangle entries (row part left of j, column part
-        // right of j+1) from the tiles or from the exchanged row-panel, patched with the pending pairs in slot order
-        double m0, m1;
-        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
-        else if (c <= j) { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
-        else if (c >= j + 2) { m0 = pmm_low<TS>(tiles, st.tm, c, j); m1 = pmm_low<TS>(tiles, st.tm, c, j + 1); }
-        else { m0 = pmm_low<TS>(tiles, st.tm, j + 1, j); m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1); }   // c == j + 1
-        if (do_patch) {
-            const int64_t ps2 = st.pair_stride / 2;
-            if (c <= j) {
-                // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
-                const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
-                int i = 0;
-                for (; i + 8 <= npend; i += 8) {
-                    double2 g[8];
+    if (live && do_patch) {
+        const int64_t ps2 = st.pair_stride / 2;
+        if (c <= j) {
+            // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
+            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
+            int i = 0;
+            for (; i + 8 <= npend; i += 8) {
+                double2 g[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)(i + q) * ps2];
+                for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)ring_slot(pstart, i + q, st.pcap) * ps2];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        m0 = rank2_apply(m0, upatch[4 * (i + q) + 0], g[q]);
-                        m1 = rank2_apply(m1, upatch[4 * (i + q) + 1], g[q]);
-                    }
-                }
-                for (; i < npend; ++i) {
-                    const double2 g = gp[(int64_t)i * ps2];
-                    m0 = rank2_apply(m0, upatch[4 * i + 0], g);
-                    m1 = rank2_apply(m1, upatch[4 * i + 1], g);
-                }
-            } else if (c >= j + 2) {
-                const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
-                int i = 0;
-                for (; i + 8 <= npend; i += 8) {
-                    double2 k[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)(i + q) * ps2];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        m0 = rank2_apply(m0, k[q], upatch[4 * (i + q) + 2]);
-                        m1 = rank2_apply(m1, k[q], upatch[4 * (i + q) + 3]);
-                    }
-                }
-                for (; i < npend; ++i) {
-                    const double2 k = kp[(int64_t)i * ps2];
-                    m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
-                    m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
-                }
-            } else {                                               // c == j + 1: canonical (j+1,j) and (j+1,j+1)
-                for (int i = 0; i < npend; ++i) {
-                    m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
-                    m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+                for (int q = 0; q < 8; ++q) {
+                    m0 = rank2_apply(m0, upatch[4 * (i + q) + 0], g[q]);
+                    m1 = rank2_apply(m1, upatch[4 * (i + q) + 1], g[q]);
                 }
             }
+            for (; i < npend; ++i) {
+                const double2 g = gp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
+                m0 = rank2_apply(m0, upatch[4 * i + 0], g);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], g);
+            }
+        } else if (c >= j + 2) {
+            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
+            int i = 0;
+            for (; i + 8 <= npend; i += 8) {
+                double2 k[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)ring_slot(pstart, i + q, st.pcap) * ps2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    m0 = rank2_apply(m0, k[q], upatch[4 * (i + q) + 2]);
+                    m1 = rank2_apply(m1, k[q], upatch[4 * (i + q) + 3]);
+                }
+            }
+            for (; i < npend; ++i) {
+                const double2 k = kp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
+                m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
+            }
+        } else {                                               // c == j + 1: canonical (j+1,j) and (j+1,j+1)
+            for (int i = 0; i < npend; ++i) {
+                m0 = rank2_apply(m0, upatch[4 * i + 1], upatch[4 * i + 2]);
+                m1 = rank2_apply(m1, upatch[4 * i + 1], upatch[4 * i + 3]);
+            }
         }
-        double s0 = strip[c], s1 = strip[ldm + c];
-        const double s2 = strip[2 * ldm + c];
+    }
+    __syncthreads();
+
+    // (4) the column's share of G, K, x and the strip
+    const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
+    const int64_t out_off = (int64_t)ring_slot(pstart, npend, st.pcap) * st.pair_stride;   // this correction's own pair
+    double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + out_off);
+    double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + out_off);
+    if (live) {
         if (kPredict) predict_strip(s0, s1, s2, ps.fa, ps.fb);
         double g[2];
         for (int r = 0; r < 2; ++r)
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
         Gout[c] = make_double2(g[0], g[1]);
         Kout[c] = make_double2(k0, k1);
-        st.x[nxt][3 + c] = x[3 + c] + (k0 * sol.nu[0] + k1 * sol.nu[1]);
+        st.x[nxt][3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
         double *__restrict__ sn = st.strip[nxt];
         sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
         sn[ldm + c] = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
@@ -527,10 +541,10 @@ template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
 template <typename TS, int T, int kSlab>
-__global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, const int2 *__restrict__ work,
-                                                     int64_t nwork, const double *__restrict__ Kp,
-                                                     const double *__restrict__ Gp, int64_t pair_stride, int npairs,
-                                                     TileMap tm) {
+__global__ __launch_bounds__(kBlock) void k_downdate(const TS *__restrict__ tiles, TS *__restrict__ dst,
+                                                     const int2 *__restrict__ work, int64_t nwork,
+                                                     const double *__restrict__ Kp, const double *__restrict__ Gp,
+                                                     int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
     // kSlab = rows of a tile one workgroup handles (T = whole tile); a work item is (tile, slab).
     // npairs pending (K_i, G_i) pairs are applied, in slot order, to registers between ONE load and ONE
     // store of every element: one pass over P for npairs update-steps.
@@ -549,7 +563,9 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
         const int64_t w = it / kSlabsPerTile;
         const int slab = (int)(it - w * kSlabsPerTile);
         const int2 ij = work[w];
-        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)slab * kSlab * T;
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)slab * kSlab * T;
+        const TS *__restrict__ tp = tiles + toff;
+        TS *__restrict__ td = dst + toff;
         double2 v[kPasses];
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
@@ -562,8 +578,9 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
         const int64_t gcol = (int64_t)ij.y * T + 2 * cp;
         const int64_t krow = (int64_t)ij.x * T + slab * kSlab;
         for (int i = 0; i < npairs; ++i) {
-            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + (int64_t)i * pair_stride) + gcol;
-            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)i * pair_stride) + krow;
+            const int64_t so = (int64_t)ring_slot(pstart, i, pcap) * pair_stride;
+            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + so) + gcol;
+            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + so) + krow;
             const double2 ga = g2[0], gb = g2[1];                  // (G1,G2) at columns 2cp and 2cp+1
 #pragma unroll
             for (int p = 0; p < kPasses; ++p) {
@@ -581,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate(TS *__restrict__ tiles, con
             if (kExact || r < kSlab) {
                 V2 o;
                 o.x = (TS)v[p].x; o.y = (TS)v[p].y;
-                *reinterpret_cast<V2 *>(tp + r * T + 2 * cp) = o;
+                *reinterpret_cast<V2 *>(td + r * T + 2 * cp) = o;
             }
         }
     }
@@ -604,10 +621,10 @@ __device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
 }
 
 template <typename TS, int T, int kSlab, bool kXcd>
-__global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, const int2 *__restrict__ work,
-                                                       int64_t nwork, const double *__restrict__ Kp,
-                                                       const double *__restrict__ Gp, int64_t pair_stride, int npairs,
-                                                       TileMap tm) {
+__global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ tiles, TS *__restrict__ dst,
+                                                       const int2 *__restrict__ work, int64_t nwork,
+                                                       const double *__restrict__ Kp, const double *__restrict__ Gp,
+                                                       int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
     using VL = typename Lane16<TS>::type;
     constexpr int kCols = Lane16<TS>::kCols;              // columns per lane: 2 (f64 tiles) or 4 (f32 tiles)
     constexpr int kLanesPerRow = T / kCols;               // 64: one row per wave instruction; 32: two rows
@@ -632,7 +649,9 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, c
         const int2 ij = work[kXcd ? (it & 7) * nwork + w : w];
         if (kXcd && ij.x < 0) continue;
         const int row0 = slab * kSlab + wave * kRowsPerWave;            // first tile row of this wavefront
-        TS *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + kCols * cl;
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + sub) * T + kCols * cl;
+        const TS *__restrict__ tp = tiles + toff;
+        TS *__restrict__ td = dst + toff;
         double v[kPasses][kCols];
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
@@ -642,8 +661,9 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, c
         const int64_t gcol = (int64_t)ij.y * T + kCols * cl;
         const int64_t krow = (int64_t)ij.x * T + row0;                  // wave-uniform
         for (int i = 0; i < npairs; ++i) {
-            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + (int64_t)i * pair_stride) + gcol;
-            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)i * pair_stride) + krow;
+            const int64_t so = (int64_t)ring_slot(pstart, i, pcap) * pair_stride;
+            const double2 *__restrict__ g2 = reinterpret_cast<const double2 *>(Gp + so) + gcol;
+            const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + so) + krow;
             double2 g[kCols];                                           // (G1,G2) at this lane's columns
 #pragma unroll
             for (int q = 0; q < kCols; ++q) g[q] = g2[q];
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(TS *__restrict__ tiles, c
         for (int p = 0; p < kPasses; ++p) {
             VL o;
             lane16_pack(v[p], o);
-            *reinterpret_cast<VL *>(tp + (int64_t)p * kRowsPerInstr * T) = o;
+            *reinterpret_cast<VL *>(td + (int64_t)p * kRowsPerInstr * T) = o;
         }
     }
 }
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
         const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
         for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b)
-            pss[15 + 2 * t + b] = have_diag ? pmm_live<TS>(tiles, st, a.npend, j + t, j + b) : NAN;
+            pss[15 + 2 * t + b] = have_diag ? pmm_live<TS>(tiles, st, a.pstart, a.npend, j + t, j + b) : NAN;
         for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
         SmallSolve sol;
@@ -930,13 +950,14 @@ int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm) {
     return k0 >= nt ? 0 : (nt - k0 + tm.world - 1) / tm.world;
 }
 
-hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int npend, double *send, int storage, hipStream_t s) {
+hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
+                           hipStream_t s) {
     const int64_t nloc = rowpanel_local_chunks(st.tm, j, n_mm);
     if (nloc == 0) return hipSuccess;
     const int64_t grid = cdiv(nloc * st.tm.T, kBlock);
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, npend, send, nloc),
-        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, npend, send, nloc));
+        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc),
+        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc));
     return hipGetLastError();
 }
 
@@ -962,10 +983,10 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // per-pair loop then carries only LDS reads and the scalar K loads -- no vector-memory wait inside it.
 // Measured at 10k landmarks, 32 pairs: 0.77 ms vs 0.91 ms (profiles/round1_tuning.md, sweep 5).
 template <int kChunk>
-__global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles, const int2 *__restrict__ work,
-                                                      int64_t nwork, const double *__restrict__ Kp,
-                                                      const double *__restrict__ Gp, int64_t pair_stride, int npairs,
-                                                      TileMap tm) {
+__global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__ tiles, double *__restrict__ dst,
+                                                      const int2 *__restrict__ work, int64_t nwork,
+                                                      const double *__restrict__ Kp, const double *__restrict__ Gp,
+                                                      int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
     constexpr int T = 128, kSlab = 32, kRowsPerWave = 8, kSlabsPerTile = 4;
     __shared__ double2 Gs[kChunk][T];
     const int tid = threadIdx.x;
@@ -979,7 +1000,9 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles
         const int2 ij = work[(it & 7) * nwork + w];
         if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
         const int row0 = slab * kSlab + wave * kRowsPerWave;
-        double *__restrict__ tp = tiles + tm.tile_offset(ij.x, ij.y) + (int64_t)row0 * T + 2 * lane;
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)row0 * T + 2 * lane;
+        const double *__restrict__ tp = tiles + toff;
+        double *__restrict__ td = dst + toff;
         double2 v[kRowsPerWave];
 #pragma unroll
         for (int p = 0; p < kRowsPerWave; ++p) v[p] = *reinterpret_cast<const double2 *>(tp + (int64_t)p * T);
@@ -995,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles
                 for (int q = 0; q < kPer; ++q) {                      // all loads in flight before the first LDS write
                     const int e = tid + q * kBlock, col = e & (T - 1);
                     const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;  // clamp: always a valid pair, written only if in range
-                    tmp[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)(c0 + i) * pair_stride)[gcol0 + col];
+                    tmp[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
                 }
 #pragma unroll
                 for (int q = 0; q < kPer; ++q) {
@@ -1005,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles
             }
             __syncthreads();
             for (int i = 0; i < cn; ++i) {
-                const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)(c0 + i) * pair_stride) + krow;
+                const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride) + krow;
                 const double2 ga = Gs[i][2 * lane], gb = Gs[i][2 * lane + 1];
 #pragma unroll
                 for (int p = 0; p < kRowsPerWave; ++p) {
@@ -1016,13 +1039,13 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(double *__restrict__ tiles
             }
         }
 #pragma unroll
-        for (int p = 0; p < kRowsPerWave; ++p) *reinterpret_cast<double2 *>(tp + (int64_t)p * T) = v[p];
+        for (int p = 0; p < kRowsPerWave; ++p) *reinterpret_cast<double2 *>(td + (int64_t)p * T) = v[p];
     }
 }
 
 template <typename TS, int T, int kSlab>
-static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                                     int npairs, int grid_cap, hipStream_t s) {
+static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
+                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
     if constexpr (kLanes == 64 || kLanes == 32) {
@@ -1031,27 +1054,27 @@ static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64
             if (npairs > 1 && use_xcd && use_lds && work_xcd && xcd_len > 0) {
                 int64_t grid = 8 * xcd_len * 4;
                 if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-                hipLaunchKernelGGL((k_flush_lds<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (double *)st.tiles, work_xcd, xcd_len,
-                                   st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+                hipLaunchKernelGGL((k_flush_lds<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
+                                   work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
                 return hipGetLastError();
             }
         }
         if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
             int64_t grid = 8 * xcd_len * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles,
-                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
+                               (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
         } else {
             int64_t grid = nwork * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles,
-                               work, nwork, st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
+                               (TS *)dstv, work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
         }
     } else {
         int64_t grid = nwork * (T / kSlab);
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-        hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (TS *)st.tiles, work, nwork,
-                           st.Kp, st.Gp, st.pair_stride, npairs, st.tm);
+        hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                           work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
     }
     return hipGetLastError();
 }
@@ -1064,11 +1087,11 @@ static hipError_t launch_downdate_ts(const DevState &st, const int2 *work, int64
 // Production tiles: T = 128 for f64 storage, T = 256 for f32 storage (one 1 KiB tile row per wave instruction,
 // K wave-uniform); T = 16 / 32 (generic kernel) and T = 64 exist for small maps and tests.
 template <typename TS>
-static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                                    int npairs, int grid_cap, int slab, hipStream_t s) {
+static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
+                                    int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, s)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -1093,13 +1116,13 @@ static hipError_t launch_downdate_t(const DevState &st, const int2 *work, int64_
 #undef EKF_DD
 }
 
-hipError_t launch_downdate(const DevState &st, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int npairs, int storage, int grid_cap, hipStream_t s) {
+hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s) {
     static const int slab1 = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
     static const int slabm = [] { const char *v = getenv("EKF_DOWNDATE_SLAB_BATCH"); return v ? atoi(v) : 0; }();
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, slab, s)
-                        : launch_downdate_t<float>(st, work, nwork, work_xcd, xcd_len, npairs, grid_cap, slab, s);
+    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s)
+                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

@@ -68,7 +68,11 @@ typedef struct ekf_config {
                                     pairs (the rows later corrections need are patched on the fly) and applied
                                     to P in ONE pass; results are bit-identical to batch = 1.  0 or 1 = every
                                     correction rewrites P immediately (EKF_SLAM.m:145 as written); max 64  */
-    int32_t reserved[7];
+    int32_t async_flush;         /* with batch > 1: run each pass over P on a second stream, from the current tile
+                                    store into a second one (2x tile memory), while the next corrections go on
+                                    reading the current store plus all pending pairs; stores swap at the next
+                                    batch boundary.  Same bits as async_flush = 0.                          */
+    int32_t reserved[6];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;

@@ -30,31 +30,35 @@ def test_deferred_equals_immediate_bitwise(batch, tile, oracle_lib):
     x, P, s = _state(N, 41)
     imm = Engine(capacity=N + 30, tile=tile, batch=1)
     dfr = Engine(capacity=N + 30, tile=tile, batch=batch)
+    asy = Engine(capacity=N + 30, tile=tile, batch=batch, async_flush=True)     # flush on a second stream, two tile stores
     ref = StructuredEKF(N + 30, "known")
-    for e in (imm, dfr, ref):
+    for e in (imm, dfr, asy, ref):
         e.set_state(x, P, s)
     rng = np.random.default_rng(8)
     for step in range(37):
         u = [0.1, 3.0]
-        for e in (imm, dfr, ref):
+        for e in (imm, dfr, asy, ref):
             e.predict(u)
         for _ in range(int(rng.integers(1, 4))):
             idx0 = int(rng.integers(0, imm.N))
             z = [rng.uniform(1, 30), rng.uniform(1, 359)]
             R = np.diag([z[0] * .01, z[1] * 5.0])
-            imm.correct(z, R, idx0); dfr.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+            imm.correct(z, R, idx0); dfr.correct(z, R, idx0); asy.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
         if step % 5 == 2:                  # grow the map while pairs are pending
             pos, sig = rng.uniform(-5, 5, 2), imm.N + 1
             R = np.diag([0.2, 40.0])
-            for e in (imm, dfr, ref):
+            for e in (imm, dfr, asy, ref):
                 e.append(u, R, pos, sig)
             z = [rng.uniform(1, 30), rng.uniform(1, 359)]
-            imm.correct(z, R, imm.N - 1); dfr.correct(z, R, dfr.N - 1); ref.correct(z, R, ref.N)
+            imm.correct(z, R, imm.N - 1); dfr.correct(z, R, dfr.N - 1); asy.correct(z, R, asy.N - 1); ref.correct(z, R, ref.N)
         np.testing.assert_array_equal(dfr.get_x(), imm.get_x())      # x is always current, no flush involved
+        np.testing.assert_array_equal(asy.get_x(), imm.get_x())
     assert batch == 2 or dfr.pending() > 0 or batch > 37
     Pd, Pi = dfr.get_P(), imm.get_P()                                 # get_P flushes
     assert dfr.pending() == 0
     np.testing.assert_array_equal(Pd, Pi)
+    np.testing.assert_array_equal(asy.get_P(), Pi)
+    assert asy.pending() == 0
     assert rel_err(Pd, ref.P) < REL and rel_err(dfr.get_x(), ref.x) < REL
     np.testing.assert_allclose(dfr.digest(), imm.digest(), rtol=1e-13)
 
@@ -90,13 +94,13 @@ def test_deferred_association_costs_see_pending_pairs(oracle_lib):
     assert e.pending() == 5
 
 
-@pytest.mark.parametrize("world,batch", [(2, 4), (3, 7), (4, 16)])
-def test_deferred_sharded_bitwise(world, batch):
+@pytest.mark.parametrize("world,batch,asy", [(2, 4, False), (3, 7, False), (4, 16, False), (2, 4, True), (3, 5, True)])
+def test_deferred_sharded_bitwise(world, batch, asy):
     from ekf_slam_amd import Engine
     from ekf_slam_amd.sharding import ShardGroup
     N = 120
     x, P, s = _state(N, 47)
-    g = ShardGroup(world, capacity=N + 8, tile=16, batch=batch)
+    g = ShardGroup(world, capacity=N + 8, tile=16, batch=batch, async_flush=asy)
     one = Engine(capacity=N + 8, tile=16, batch=1)
     g.set_state(x, P, s); one.set_state(x, P, s)
     rng = np.random.default_rng(6)

@@ -2,7 +2,7 @@
 steps on a full 20 003 x 20 003 matrix (3.2 GB); parity is checked on x (all of it), on the digests of P
 (trace / sum / sum of squares over the lower triangle), on the robot rows and on sampled blocks spread over first,
 middle and last tile rows, plus size-independent properties: trace non-increasing across a correction, and the
-deferred engine (batch 8) equal to the immediate one bit for bit."""
+deferred engine (batch 4, asynchronous flush) equal to the immediate one bit for bit."""
 import numpy as np
 import pytest
 
@@ -32,7 +32,7 @@ def test_ten_thousand_landmarks_against_oracle(oracle_lib):
     ref._x[:n] = x; ref._s[:N] = s
     ref.L.oekf_set_num_landmarks(ref.h, N)
     imm = Engine(capacity=N, batch=1)
-    dfr = Engine(capacity=N, batch=8)
+    dfr = Engine(capacity=N, batch=4, async_flush=True)      # 9 corrections: two asynchronous flushes + one pending pair
     for e in (imm, dfr):
         e.load_lowrank_state(x, s, d, U)
     tr0 = imm.digest()[0]
@@ -47,7 +47,7 @@ def test_ten_thousand_landmarks_against_oracle(oracle_lib):
         if t == 4:
             traces.append(imm.digest()[0])
     assert traces[2] <= traces[1] + 1e-9          # a correction never increases trace(P)
-    assert dfr.pending() == 1                     # 9 corrections, batch 8: one pair still pending
+    assert dfr.pending() in (1, 5)                # 9 corrections, batch 4: one new pair (+ 4 of a flush still in flight)
     xg = imm.get_x()
     np.testing.assert_array_equal(dfr.get_x(), xg)
     assert rel_err(xg, ref._x[:n]) < REL
