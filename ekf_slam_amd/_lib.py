@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libekfslam.so")
+LIB_PATH = os.environ.get("EKF_LIB_PATH") or os.path.join(_HERE, "libekfslam.so")   # override: A/B builds
 
 EKF_OK = 0
 EKF_ERR_INVALID_ARG, EKF_ERR_NO_DEVICE, EKF_ERR_HIP, EKF_ERR_CAPACITY = 1, 2, 3, 4

@@ -83,15 +83,20 @@ __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, i
 // bit-identical results.  in: pose[3], M = Prr (row-major); out: fa = F(1,3), fb = F(2,3), new pose, Prr' , Q.
 struct PredictSmall { double fa, fb; double pose[3]; double prr[9]; double Q[9]; };
 
-// noinline: ONE machine-code body shared by every kernel that needs it, so that the standalone predict and the predict
-// folded into a correction cannot differ by a rounding (inlined copies did: different libm expansion per context)
-__device__ __attribute__((noinline)) void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
-                                     PredictSmall &o) {
+// The only pieces whose results depend on how the compiler expands them are the libm calls (inlined copies of
+// sin/cos/atan2 gave different last bits in different kernels).  They live in noinline wrappers -- ONE machine-code
+// body shared by every kernel -- so that the standalone predict, the predict folded into a correction and the
+// association kernel cannot differ by a rounding.  Everything else is plain IEEE arithmetic (-ffp-contract=off).
+__device__ __attribute__((noinline)) void sincosd_ni(double a, double &sn, double &cs) { ekfm::sincosd(a, sn, cs); }
+__device__ __attribute__((noinline)) double bearing_ni(double d1, double d0, double th) {
+    return ekfm::wrapTo360(ekfm::atan2d(d1, d0) - th);                                // EKF_SLAM.m:130
+}
+
+// predict, given sind/cosd of the pre-motion heading (sn, cs) and of heading + u2 (sn2, cs2)
+__device__ __forceinline__ void predict_finish(const double pose[3], const double prr_in[9], double u0, double u1, double C,
+                                               double sn, double cs, double sn2, double cs2, PredictSmall &o) {
     const double th = pose[2];
     // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
-    double sn, cs, sn2, cs2;
-    ekfm::sincosd(th, sn, cs);
-    ekfm::sincosd(th + u1, sn2, cs2);
     o.fa = -1 * u0 * sn;
     o.fb = u0 * cs;
     const double W[3] = { u0 * cs, u0 * sn, u1 };                                     // EKF_SLAM.m:42
@@ -105,6 +110,14 @@ __device__ __attribute__((noinline)) void predict_small(const double pose[3], co
     o.pose[0] = pose[0] + u0 * cs2;                                                   // EKF_SLAM.m:58-60
     o.pose[1] = pose[1] + u0 * sn2;
     o.pose[2] = ekfm::wrapTo360(th + u1);                                             // EKF_SLAM.m:50
+}
+
+__device__ __forceinline__ void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
+                                              PredictSmall &o) {
+    double sn, cs, sn2, cs2;
+    sincosd_ni(pose[2], sn, cs);
+    sincosd_ni(pose[2] + u1, sn2, cs2);
+    predict_finish(pose, prr_in, u0, u1, C, sn, cs, sn2, cs2, o);
 }
 
 // strip column under F*P: (F*P)(1,:) = P(1,:) + F(1,3) P(3,:), (F*P)(2,:) = P(2,:) + F(2,3) P(3,:)
@@ -259,15 +272,18 @@ struct SmallSolve {
 };
 
 // pss: 0..8 Prr row-major; 9+2t+b = P(t, j+b), t<3, b<2; 15+2t+b = canonical P(j+t, j+b); 19..21 x_r; 22..23 x_j
-__device__ __attribute__((noinline)) void solve_small(const double *pss, double z0, double z1, double R00, double R01, double R10,
-                                   double R11, SmallSolve &o) {
-    const double d0 = pss[22] - pss[19], d1 = pss[23] - pss[20];                       // EKF_SLAM.m:125-126
-    const double q = d0 * d0 + d1 * d1, sq = sqrt(q);                                  // :127
-    const double zhat0 = sq;
-    const double zhat1 = ekfm::wrapTo360(ekfm::atan2d(d1, d0) - pss[21]);              // :130
+// the measurement Jacobian block H_s from delta = landmark - robot  (EKF_SLAM.m:125-127,137-138)
+__device__ __forceinline__ void solve_hs(double d0, double d1, double &sq, double Hs[2][5]) {
+    const double q = d0 * d0 + d1 * d1;
+    sq = sqrt(q);
     const double iq = 1 / q;
     const double e[2][5] = { { -sq * d0, -sq * d1, 0, sq * d0, sq * d1 }, { d1, -d0, -q, -d1, d0 } };
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 5; ++b) o.Hs[a][b] = iq * e[a][b]; // :137-138
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 5; ++b) Hs[a][b] = iq * e[a][b];
+}
+
+// everything after H_s and the predicted measurement (zhat0 = range, zhat1 = bearing): G(:,S), phi, inv(phi), nu, K_r
+__device__ __forceinline__ void solve_rest(const double *pss, double zhat0, double zhat1, double z0, double z1, double R00,
+                                           double R01, double R10, double R11, SmallSolve &o) {
     double GS[2][5];
     for (int a = 0; a < 2; ++a) {
         for (int b = 0; b < 3; ++b) {      // robot columns: P(j+t, b) is stored as strip(b, j+t)
@@ -293,6 +309,16 @@ __device__ __attribute__((noinline)) void solve_small(const double *pss, double 
     o.nu[1] = z1 - zhat1;
     for (int b = 0; b < 3; ++b) for (int cc = 0; cc < 2; ++cc)
         o.Kr[b][cc] = o.Gr[0][b] * o.Phi[cc] + o.Gr[1][b] * o.Phi[2 + cc];
+}
+
+// serial composition (association kernel: one lane per landmark)
+__device__ __forceinline__ void solve_small(const double *pss, double z0, double z1, double R00, double R01, double R10,
+                                            double R11, SmallSolve &o) {
+    const double d0 = pss[22] - pss[19], d1 = pss[23] - pss[20];                       // EKF_SLAM.m:125-126
+    double sq;
+    solve_hs(d0, d1, sq, o.Hs);
+    const double bearing = bearing_ni(d1, d0, pss[21]);
+    solve_rest(pss, sq, bearing, z0, z1, R00, R01, R10, R11, o);
 }
 
 // Sharded source of the landmark row-panel M = P(j:j+1, landmark columns): after the all-gather every
@@ -422,28 +448,26 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     }
     __syncthreads();
 
-    // (3) lane 0: live 2x2 diagonal block, optional predict, the 2x2 solve.  Every other lane meanwhile applies the
-    //     pending pairs to its two row entries (none of that depends on the solve).
-    if (tid == 0) {
-        if (do_patch) {
-            // canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
-            double d00 = pss[15], d10 = pss[17], d11 = pss[18];
-            for (int i = 0; i < npend; ++i) {
-                d00 = rank2_apply(d00, upatch[4 * i + 0], upatch[4 * i + 2]);
-                d10 = rank2_apply(d10, upatch[4 * i + 1], upatch[4 * i + 2]);
-                d11 = rank2_apply(d11, upatch[4 * i + 1], upatch[4 * i + 3]);
-            }
-            pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
+    // (3) the scalar prologue, spread over three wavefronts so that its independent pieces run side by side (they are
+    //     long chains of dependent f64 operations on ONE lane each: ~5 us when done back to back):
+    //       wave 0: sind/cosd of the pre-motion heading      wave 1: sind/cosd of heading + u2
+    //       wave 2: the pending pairs on the 2x2 diagonal block
+    //     then wave 0 finishes the predict and forms delta; then wave 0 does sqrt / H_s while wave 1 does the atan2;
+    //     then wave 0 finishes the solve.  Meanwhile every lane applies the pending pairs to its own two row entries.
+    __shared__ double stage[8];          // 0..3: sn, cs, sn2, cs2   4..5: sqrt(q), bearing
+    if (kPredict) {
+        if (tid == 0) sincosd_ni(pss[21], stage[0], stage[1]);
+        if (tid == 64) sincosd_ni(pss[21] + pa.u1, stage[2], stage[3]);
+    }
+    if (do_patch && tid == 128) {
+        // canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
+        double d00 = pss[15], d10 = pss[17], d11 = pss[18];
+        for (int i = 0; i < npend; ++i) {
+            d00 = rank2_apply(d00, upatch[4 * i + 0], upatch[4 * i + 2]);
+            d10 = rank2_apply(d10, upatch[4 * i + 1], upatch[4 * i + 2]);
+            d11 = rank2_apply(d11, upatch[4 * i + 1], upatch[4 * i + 3]);
         }
-        if (kPredict) {
-            // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
-            const double pose[3] = { pss[19], pss[20], pss[21] };
-            predict_small(pose, pss, pa.u0, pa.u1, pa.C, ps);
-            for (int i = 0; i < 9; ++i) pss[i] = ps.prr[i];
-            for (int b = 0; b < 2; ++b) predict_strip(pss[9 + b], pss[11 + b], pss[13 + b], ps.fa, ps.fb);
-            for (int i = 0; i < 3; ++i) pss[19 + i] = ps.pose[i];
-        }
-        solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
+        pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
     }
     if (live && do_patch) {
         const int64_t ps2 = st.pair_stride / 2;
@@ -491,6 +515,20 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
             }
         }
     }
+    __syncthreads();
+    if (tid == 0 && kPredict) {
+        // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
+        const double pose[3] = { pss[19], pss[20], pss[21] };
+        predict_finish(pose, pss, pa.u0, pa.u1, pa.C, stage[0], stage[1], stage[2], stage[3], ps);
+        for (int i = 0; i < 9; ++i) pss[i] = ps.prr[i];
+        for (int b = 0; b < 2; ++b) predict_strip(pss[9 + b], pss[11 + b], pss[13 + b], ps.fa, ps.fb);
+        for (int i = 0; i < 3; ++i) pss[19 + i] = ps.pose[i];
+    }
+    if (kPredict) __syncthreads();
+    if (tid == 0) solve_hs(pss[22] - pss[19], pss[23] - pss[20], stage[4], sol.Hs);   // EKF_SLAM.m:125-127,137-138
+    if (tid == 64) stage[5] = bearing_ni(pss[23] - pss[20], pss[22] - pss[19], pss[21]);
+    __syncthreads();
+    if (tid == 0) solve_rest(pss, stage[4], stage[5], a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
     __syncthreads();
 
     // (4) the column's share of G, K, x and the strip
