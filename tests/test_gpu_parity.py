@@ -173,3 +173,51 @@ def test_error_statuses():
     with pytest.raises(EkfError) as ei:
         e2.measure([[1.0, 10.0, 1.0]], [0.1, 1.0], [1.0, 2.0], [[0, 0], [1, 1]])
     assert ei.value.status == L.EKF_ERR_LOOKUP
+
+
+def test_measure_with_position_weighted_association(oracle_lib):
+    """w_pos = 1 is the commented-out likelihood of Correspondence.m:74 (Mahalanobis + signature): measure() must then
+    run the device association kernels (the host mirror of s cannot decide), and agree with the oracle."""
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle.ekf_structured import StructuredEKF
+    _, run = make_run(30, 31, 14, policy="nearest", m=5)
+    # a threshold that lets the position cost matter but still associates re-observed landmarks
+    gpu = EKF_SLAM_UC(capacity=32, tile=16, batch=4, w_pos=1.0, s_thresh=1e12)
+    ref = StructuredEKF(32, "uc", w_pos=1.0, s_thresh=1e12)
+    lg, lr = Landmark('SYNTHETIC'), SyntheticLandmark()
+    for u, scan in run:
+        gpu.predict(u); ref.predict(u)
+        gpu.measure(scan, u, lg); ref.measure(scan, u, lr)
+        assert gpu._e.N == ref.N
+    assert rel_err(gpu.x, ref.x) < REL and rel_err(gpu.P, ref.P) < REL
+    np.testing.assert_array_equal(gpu.s, ref.s)
+
+
+def test_soak_2000_update_steps_ring_and_throttle(oracle_lib):
+    """A longer run (500 iterations x 4 observations at 300 landmarks, batch 7): exercises the pending-pair ring wrap,
+    the run-ahead throttle and repeated flushes; final state against the oracle."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 300
+    x, P, s, _, _ = _random_spd_state(N, 71)
+    e = Engine(capacity=N, batch=7, async_flush=True)
+    e2 = Engine(capacity=N, batch=7)
+    ref = StructuredEKF(N, "known")
+    for o in (e, e2, ref):
+        o.set_state(x, P, s)
+    rng = np.random.default_rng(19)
+    for it in range(500):
+        u = [0.05, 1.0 + 0.01 * (it % 7)]
+        for o in (e, e2, ref):
+            o.predict(u)
+        for _ in range(4):
+            idx0 = int(rng.integers(0, N))
+            z = [rng.uniform(1, 30), rng.uniform(20, 340)]
+            R = np.diag([z[0] * .01, z[1] * 5.0])
+            e.correct(z, R, idx0); e2.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+    np.testing.assert_array_equal(e.get_x(), e2.get_x())
+    np.testing.assert_array_equal(e.get_P(), e2.get_P())
+    assert np.isfinite(e.get_x()).all()
+    assert rel_err(e.get_x(), ref.x) < REL and rel_err(e.get_P(), ref.P) < REL
+    print("soak: x %.2e P %.2e" % (rel_err(e.get_x(), ref.x), rel_err(e.get_P(), ref.P)))
