@@ -27,12 +27,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("ekfslam:usage", "command string expected");
     (void)nlhs;
 
-    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile]) */
+    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile [, batch]]) */
         ekf_config cfg;
         ekf_handle *h = NULL;
         check(NULL, ekf_config_default(&cfg, (int32_t)mxGetScalar(prhs[1])));
         cfg.capacity_landmarks = (int64_t)mxGetScalar(prhs[2]);
         if (nrhs > 3) cfg.tile = (int32_t)mxGetScalar(prhs[3]);
+        if (nrhs > 4) cfg.batch = (int32_t)mxGetScalar(prhs[4]);      /* deferred downdate, same results */
         int32_t rc = ekf_create(&cfg, &h);
         if (rc != EKF_OK) { const char *m = h ? ekf_last_error(h) : ""; mexErrMsgIdAndTxt("ekfslam:status", "%s: %s", ekf_status_string(rc), m); }
         plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
