@@ -15,7 +15,7 @@ Two legs are measured in the same invocation:
   * `immediate`: cfg.batch = 1, every correction rewrites P at once (EKF_SLAM.m:145 as written); this is the
     leg whose downdate kernel is purely HBM-bound and is compared with the 8 TB/s roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 28]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 24]
 
 For N > 1 launch one rank per GPU (torch.distributed.run); P is split over the ranks (tile (I,J) on rank
 (I+J) mod N) and each update-step carries one all-gather of the 2 x n landmark row-panel.
@@ -105,13 +105,13 @@ def load_traffic(N, tile, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=288)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=28,
-                    help="corrections per pass over P (headline leg); 28 is the largest batch whose pass stays above 60 %% "
-                         "of the HBM roofline (profiles/round1_tuning.md, sweeps 8-9)")
+    ap.add_argument("--batch", type=int, default=24,
+                    help="corrections per pass over P (headline leg); 24 keeps the pass at ~62 %% of the HBM roofline, 28 is "
+                         "borderline 60 %%, 32 is ~57 %% with ~12 %% more update-steps/s (profiles/round1_tuning.md, sweeps 8-9)")
     ap.add_argument("--async-flush", action="store_true",
                     help="run each pass over P on a second stream into a second tile store (measured: no gain, see "
                          "profiles/round1_tuning.md sweep 6)")
