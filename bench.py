@@ -15,7 +15,7 @@ Two legs are measured in the same invocation:
   * `immediate`: cfg.batch = 1, every correction rewrites P at once (EKF_SLAM.m:145 as written); this is the
     leg whose downdate kernel is purely HBM-bound and is compared with the 8 TB/s roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 24]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 32]
 
 For N > 1 launch one rank per GPU (torch.distributed.run); P is split over the ranks (tile (I,J) on rank
 (I+J) mod N) and each update-step carries one all-gather of the 2 x n landmark row-panel.
@@ -105,13 +105,13 @@ def load_traffic(N, tile, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=288)
-    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=24,
-                    help="corrections per pass over P (headline leg); 24 keeps the pass at ~62 %% of the HBM roofline, 28 is "
-                         "borderline 60 %%, 32 is ~57 %% with ~12 %% more update-steps/s (profiles/round1_tuning.md, sweeps 8-9)")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="corrections per pass over P (headline leg); with the MFMA flush 32 keeps the pass at ~64 %% of the HBM "
+                         "roofline, 24 at ~70 %% with ~10 %% fewer update-steps/s (profiles/round1_tuning.md, sweep 10)")
     ap.add_argument("--async-flush", action="store_true",
                     help="run each pass over P on a second stream into a second tile store (measured: no gain, see "
                          "profiles/round1_tuning.md sweep 6)")
@@ -221,7 +221,7 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
                 "traffic": load_traffic(N, args.tile, batch) if world == 1 else None,
-                "kernel": "k_downdate_w" if args.tile >= 64 else "k_downdate", "launches": launches,
+                "kernel": ("k_flush_mfma" if (batch > 1 and args.tile == 128) else "k_downdate_w" if args.tile >= 64 else "k_downdate"), "launches": launches,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg_rank,
                 "update_steps_per_launch": nsteps / max(launches, 1)}
         return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "roofline": roof, "transport": transport,

@@ -160,10 +160,10 @@ __global__ __launch_bounds__(kBlock) void k_predict(DevState st, PredictArgs a) 
 // F_rr (3x3) * strip (3 x 2N).  One v_mfma_f64_16x16x4_f64 per wavefront and 16 columns: A = F_rr zero-padded to
 // 16x4 (lane l holds A[l&15][l>>4]), B = a 4x16 slice of the strip with a zero 4th row (lane l holds
 // B[l>>4][l&15]), D row (l>>4) + 4*reg, column l&15 -> register 0 of lanes 0..47 is the new 3x16 slice.
-// The f64 MFMA is NOT a k-ordered FMA chain: against predict_strip()'s fma(fa, s2, s0) it differs in the last bit
-// for about one entry in six (measured, tests/test_deferred_gpu.py), i.e. the two predict paths agree to
-// rounding (1e-15), not bit for bit.  The panel is 3 x 2N and costs < 1 % of an update-step, so this is about
-// using the matrix unit for the one GEMM-shaped piece of the path, not about speed.
+// The f64 MFMA is a k-ordered chain of correctly rounded FMAs (scripts/probes/mfma_f64_order.*): with the unit / F(1:2,3)
+// operands above it computes fma(fa, s2, fma(0, s1, fma(1, s0, 0))) = fma(fa, s2, s0), i.e. exactly predict_strip() -- the
+// standalone and the fused predict agree bit for bit (tests/test_deferred_gpu.py).  The panel is 3 x 2N and costs < 1 % of
+// an update-step, so this is about using the matrix unit for a GEMM-shaped piece of the path, not about speed.
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(kBlock) void k_predict_mfma(DevState st, PredictArgs a) {
@@ -1089,6 +1089,117 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__
     }
 }
 
+// Batched flush on the matrix cores (f64 tiles, T = 128) -- the production flush for two or more pending pairs.
+// P_tile -= K_rows (64 x 2m) * G_cols (2m x 128) is a rank-2m update; v_mfma_f64_16x16x4_f64 applies four of its 2m
+// rank-1 terms per instruction.  The instruction is a k-ordered chain of correctly rounded FMAs,
+//     D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))
+// (scripts/probes/mfma_f64_order.{hip,py}: 4096/4096 elements bit-equal to that chain and to no other order), so with
+// A = -K (negation is exact) and the k index running (pair 0: x, y), (pair 1: x, y), ... in ring order the result is
+// bit-identical to rank2_apply() applied pair after pair -- i.e. to the immediate (batch = 1) downdate.
+// Mapping: a workgroup owns 64 rows x 128 columns of a tile, a wavefront 16 rows x 128 columns = 8 accumulator blocks
+// (32 f64 per lane).  The MFMA "column" lane&15 of block (bp, e) is the PHYSICAL column 32*bp + 2*(lane&15) + e, so
+// every lane still loads / stores 16 contiguous bytes of a tile row.  -K and G of a chunk of kChunk pairs are staged
+// through LDS once per workgroup, de-interleaved to [k][row] / [k][col]; the per-k-step cost is one ds_read_b64 (A)
+// and four ds_read_b128 (B) per 8 MFMAs.  An odd pair count is padded with A = -0.0, B = +0.0 (x + (-0) == x
+// for every x, signed zeros included).
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Two instances: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~24 pairs, where the pass is HBM-bound
+// and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond, where the
+// f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
+template <int kChunk>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChunk <= 4 ? 4 : 3, kChunk <= 4 ? 4 : 3)))
+void k_flush_mfma(const double *__restrict__ tiles, double *__restrict__ dst,
+                                                       const int2 *__restrict__ work, int64_t nwork,
+                                                       const double *__restrict__ Kp, const double *__restrict__ Gp,
+                                                       int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
+    constexpr int T = 128, kRows = 64, kSlabsPerTile = T / kRows, kKPad = kRows + 16;
+    static_assert(kChunk % 2 == 0 && (kChunk * T) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
+    __shared__ __attribute__((aligned(16))) double Gs[2 * kChunk][T];
+    __shared__ double Ks[2 * kChunk][kKPad];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane >> 4, lc = lane & 15;                        // MFMA k / row-group index, MFMA row / column index
+    const int64_t nitems = 8 * nwork * kSlabsPerTile;                 // 8 per-XCD streams (see k_downdate_w)
+    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int64_t vi = it >> 3;
+        const int64_t w = vi / kSlabsPerTile;
+        const int slab = (int)(vi - w * kSlabsPerTile);
+        const int2 ij = work[(it & 7) * nwork + w];
+        if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
+        const int row0 = slab * kRows + wave * 16;
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + lr) * T + 2 * lc;
+        const double *__restrict__ tp = tiles + toff;
+        double *__restrict__ td = dst + toff;
+        d4_t acc[4][2];                                               // [column group bp][column parity e][row r -> row0 + lr + 4r]
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[bp][0][r] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 32 * bp);
+                acc[bp][1][r] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 32 * bp + 1);
+            }
+        const int64_t gcol0 = (int64_t)ij.y * T;
+        const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
+        constexpr int kPerG = kChunk * T / kBlock, kPerK = kChunk * kRows / kBlock;
+        double2 tg[kPerG], tk[kPerK];                                 // the NEXT chunk's operands, in flight while this one is applied
+        auto fetch = [&](int c0, int cn) {
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, col = e & (T - 1);
+                const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;      // clamp: always a valid pair, used only if in range
+                tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
+            }
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, row = e & (kRows - 1);
+                const int i = (e >> 6) < cn ? (e >> 6) : cn - 1;
+                tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
+            }
+        };
+        fetch(0, npairs < kChunk ? npairs : kChunk);
+        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            __syncthreads();                                          // everyone is done with the previous chunk
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, i = e >> 7, col = e & (T - 1);
+                if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
+                else if (i == cn) { Gs[2 * i][col] = 0.0; Gs[2 * i + 1][col] = 0.0; }       // pad of an odd count
+            }
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, i = e >> 6, row = e & (kRows - 1);
+                if (i < cn) { Ks[2 * i][row] = -tk[q].x; Ks[2 * i + 1][row] = -tk[q].y; }
+                else if (i == cn) { Ks[2 * i][row] = -0.0; Ks[2 * i + 1][row] = -0.0; }
+            }
+            __syncthreads();
+            if (c0 + kChunk < npairs) fetch(c0 + kChunk, npairs - c0 - kChunk < kChunk ? npairs - c0 - kChunk : kChunk);
+            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
+#pragma unroll 2
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const double a = Ks[4 * ks + lr][wave * 16 + lc];
+                double2 b[4];
+#pragma unroll
+                for (int bp = 0; bp < 4; ++bp) b[bp] = *reinterpret_cast<const double2 *>(&Gs[4 * ks + lr][32 * bp + 2 * lc]);
+#pragma unroll
+                for (int bp = 0; bp < 4; ++bp) {
+                    acc[bp][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp].x, acc[bp][0], 0, 0, 0);
+                    acc[bp][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp].y, acc[bp][1], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int bp = 0; bp < 4; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __builtin_nontemporal_store(acc[bp][0][r], td + (int64_t)(4 * r) * T + 32 * bp);
+                __builtin_nontemporal_store(acc[bp][1][r], td + (int64_t)(4 * r) * T + 32 * bp + 1);
+            }
+    }
+}
+
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                      int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s) {
@@ -1097,6 +1208,19 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
     if constexpr (kLanes == 64 || kLanes == 32) {
         static const bool use_lds = [] { const char *v = getenv("EKF_FLUSH_LDS"); return !v || atoi(v) != 0; }();
         if constexpr (sizeof(TS) == 8 && T == 128 && kSlab == 32) {
+            static const bool use_mfma = [] { const char *v = getenv("EKF_FLUSH_MFMA"); return !v || atoi(v) != 0; }();
+            if (npairs > 1 && use_xcd && use_mfma && work_xcd && xcd_len > 0) {
+                int64_t grid = 8 * xcd_len * 2;
+                if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+                static const int chunk_switch = [] { const char *v = getenv("EKF_FLUSH_MFMA_SWITCH"); return v ? atoi(v) : 26; }();
+                if (npairs <= chunk_switch)
+                    hipLaunchKernelGGL((k_flush_mfma<4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
+                                       work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                else
+                    hipLaunchKernelGGL((k_flush_mfma<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
+                                       work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                return hipGetLastError();
+            }
             if (npairs > 1 && use_xcd && use_lds && work_xcd && xcd_len > 0) {
                 int64_t grid = 8 * xcd_len * 4;
                 if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: bench_variability.sh "28 32 36" 3   -> batch, steps, update-steps/s, flush ms, roofline frac per run
+for r in $(seq 1 ${2:-3}); do
+  for b in $1; do
+    timeout -k 10 200 python bench.py --batch $b --steps $((b*10)) --warmup $((b*2)) --no-cpu-baseline 2>/dev/null > /tmp/bv.json || exit 1
+    python - "$b" <<'PY'
+import json, sys
+d = json.load(open('/tmp/bv.json'))
+print(sys.argv[1], d["steps"], round(d["value"]), round(d["roofline"]["avg_launch_ms"], 4), round(d["roofline"]["frac"], 3), flush=True)
+PY
+  done
+done

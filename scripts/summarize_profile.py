@@ -41,10 +41,10 @@ write = counter_by_grid("write", "WRITE_SIZE", ("k_downdate", "k_flush"))
 legs = []
 for (kname, grid), (f_kib, nf) in sorted(fetch.items(), key=lambda kv: kv[0][1]):
     w_kib, nw = write[(kname, grid)]
-    # which leg: the immediate kernel covers 4 rows of a tile per workgroup, the batched flush 32 rows -> 8x fewer workgroups
+    # which leg: the immediate kernel covers 4 rows of a tile per workgroup, the batched flush 32 or 64 rows -> 8x / 16x fewer workgroups
     immediate = grid == max(g for (_, g) in fetch)
     batch = 1 if immediate else bench["config"]["deferred_batch"]
-    rec = {"kernel": "k_flush_lds" if "k_flush_lds" in kname else "k_downdate_w", "grid_size": grid, "landmarks": bench["config"]["landmarks"],
+    rec = {"kernel": next((k for k in ("k_flush_mfma", "k_flush_lds", "k_downdate_w") if k in kname), kname[:40]), "grid_size": grid, "landmarks": bench["config"]["landmarks"],
            "tile": bench["config"]["tile"], "batch": batch,
            "FETCH_SIZE_KiB_avg": f_kib, "fetch_dispatches": nf, "WRITE_SIZE_KiB_avg": w_kib, "write_dispatches": nw,
            "hbm_read_bytes_per_launch": 2.0 * f_kib * 1024.0, "hbm_write_bytes_per_launch": w_kib * 1024.0,

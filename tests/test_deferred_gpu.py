@@ -150,9 +150,9 @@ def test_fused_predict_equals_standalone_predict_bitwise(oracle_lib):
 
 def test_mfma_predict_panel_matches_valu_and_oracle(oracle_lib):
     """At >= 1024 landmarks the standalone predict runs its 3x3 * 3x2N panel product on v_mfma_f64_16x16x4_f64; the
-    predict folded into a correction uses plain FMAs.  The f64 MFMA is not a k-ordered FMA chain (measured: results
-    differ from fma(fa, s2, s0) in the last bit for ~1 in 6 entries), so the two paths agree to rounding, not bit for
-    bit; both are far inside the 1e-6 tolerance against the oracle."""
+    predict folded into a correction uses plain FMAs.  The f64 MFMA is a k-ordered chain of correctly rounded FMAs
+    (scripts/probes/mfma_f64_order.*), so with the identity / F(1:2,3) operands it performs exactly fma(fa, s2, s0):
+    the two paths agree bit for bit."""
     from ekf_slam_amd import Engine
     from oracle.ekf_structured import StructuredEKF
     N = 1100                                        # 2200 strip columns: MFMA path, ragged last 16-column slice
@@ -173,7 +173,33 @@ def test_mfma_predict_panel_matches_valu_and_oracle(oracle_lib):
         fused.correct(z, R, idx0); split.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
     fused.predict([0.2, 5.0]); split.predict([0.2, 5.0]); ref.predict([0.2, 5.0])
     Pf, Ps = fused.get_P(), split.get_P()
-    assert rel_err(fused.get_x(), split.get_x()) < 1e-12 and rel_err(Pf, Ps) < 1e-12
+    np.testing.assert_array_equal(fused.get_x(), split.get_x())
+    np.testing.assert_array_equal(Pf, Ps)
     assert rel_err(Pf, ref.P) < REL and rel_err(fused.get_x(), ref.x) < REL
-    assert rel_err(Ps, ref.P) < REL and rel_err(split.get_x(), ref.x) < REL
-    print("mfma vs valu: x %.2e P %.2e; vs oracle P %.2e" % (rel_err(fused.get_x(), split.get_x()), rel_err(Pf, Ps), rel_err(Ps, ref.P)))
+
+
+@pytest.mark.parametrize("batch", [2, 3, 5, 8, 9, 13, 27, 32, 33, 64])
+def test_mfma_flush_equals_immediate_bitwise(batch):
+    """Production tiles (T = 128, F64): two or more pending pairs are applied by k_flush_mfma on the matrix cores.  Odd pair
+    counts (padded k-step), chunk boundaries (4 / 8 pairs per LDS chunk, both instances) and partial final batches must all
+    reproduce the one-pair VALU downdate bit for bit, signed zeros included."""
+    from ekf_slam_amd import Engine
+    N = 300                                         # 600 landmark rows: 5 tile rows, ragged last tile
+    x, P, s = _state(N, 61)
+    imm = Engine(capacity=N, tile=128, batch=1)
+    dfr = Engine(capacity=N, tile=128, batch=batch)
+    imm.set_state(x, P, s); dfr.set_state(x, P, s)
+    rng = np.random.default_rng(batch)
+    steps = 2 * batch + 3                           # two full flushes and a partial one
+    for step in range(steps):
+        imm.predict([0.1, 2.0]); dfr.predict([0.1, 2.0])
+        idx0 = int(rng.integers(0, N))
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        imm.correct(z, R, idx0); dfr.correct(z, R, idx0)
+    assert dfr.pending() == steps % batch
+    Pd, Pi = dfr.get_P(), imm.get_P()
+    np.testing.assert_array_equal(Pd, Pi)
+    assert Pd.tobytes() == Pi.tobytes()             # signed zeros too
+    np.testing.assert_array_equal(dfr.get_x(), imm.get_x())
+    np.testing.assert_allclose(dfr.digest(), imm.digest(), rtol=1e-13)      # the digest's reduction order is not fixed
