@@ -1104,50 +1104,56 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__
 // for every x, signed zeros included).
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// Two instances: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~24 pairs, where the pass is HBM-bound
-// and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond, where the
-// f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
-template <int kChunk>
+// Two chunk sizes: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~24 pairs, where the pass is
+// HBM-bound and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond,
+// where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
+// Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
+// = 64 rows x one 128-column half; a lane's 16 bytes are 4 columns, widened to f64 on load and rounded once on store).
+template <typename TS, int T, int kChunk>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChunk <= 4 ? 4 : 3, kChunk <= 4 ? 4 : 3)))
-void k_flush_mfma(const double *__restrict__ tiles, double *__restrict__ dst,
-                                                       const int2 *__restrict__ work, int64_t nwork,
-                                                       const double *__restrict__ Kp, const double *__restrict__ Gp,
-                                                       int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
-    constexpr int T = 128, kRows = 64, kSlabsPerTile = T / kRows, kKPad = kRows + 16;
-    static_assert(kChunk % 2 == 0 && (kChunk * T) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
-    __shared__ __attribute__((aligned(16))) double Gs[2 * kChunk][T];
+void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
+                  const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
+                  int npairs, TileMap tm) {
+    constexpr int kRows = 64, kCols = 128, kKPad = kRows + 16;
+    constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
+    constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
+    constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
+    static_assert(kBP * kE == 8 && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 columns = 8 MFMA blocks");
+    static_assert(kChunk % 2 == 0 && (kChunk * kCols) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
+    __shared__ __attribute__((aligned(16))) double Gs[2 * kChunk][kCols];
     __shared__ double Ks[2 * kChunk][kKPad];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane >> 4, lc = lane & 15;                        // MFMA k / row-group index, MFMA row / column index
-    const int64_t nitems = 8 * nwork * kSlabsPerTile;                 // 8 per-XCD streams (see k_downdate_w)
+    const int64_t nitems = 8 * nwork * kSubsPerTile;                  // 8 per-XCD streams (see k_downdate_w)
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const int64_t vi = it >> 3;
-        const int64_t w = vi / kSlabsPerTile;
-        const int slab = (int)(vi - w * kSlabsPerTile);
+        const int64_t w = vi / kSubsPerTile;
+        const int sub = (int)(vi - w * kSubsPerTile);
         const int2 ij = work[(it & 7) * nwork + w];
         if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
+        const int slab = sub / kColParts, cpart = sub - slab * kColParts;
         const int row0 = slab * kRows + wave * 16;
-        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + lr) * T + 2 * lc;
-        const double *__restrict__ tp = tiles + toff;
-        double *__restrict__ td = dst + toff;
-        d4_t acc[4][2];                                               // [column group bp][column parity e][row r -> row0 + lr + 4r]
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + lr) * T + cpart * kCols + kE * lc;
+        const TS *__restrict__ tp = tiles + toff;
+        TS *__restrict__ td = dst + toff;
+        d4_t acc[kBP][kE];                                            // [16-byte group bp][column e in it][row r -> row0 + lr + 4r]
 #pragma unroll
-        for (int bp = 0; bp < 4; ++bp)
+        for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[bp][0][r] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 32 * bp);
-                acc[bp][1][r] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 32 * bp + 1);
-            }
-        const int64_t gcol0 = (int64_t)ij.y * T;
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < kE; ++e)                          // adjacent scalars: one 16-byte nontemporal load
+                    acc[bp][e][r] = (double)__builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 16 * kE * bp + e);
+        const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
         const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
-        constexpr int kPerG = kChunk * T / kBlock, kPerK = kChunk * kRows / kBlock;
+        constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
         double2 tg[kPerG], tk[kPerK];                                 // the NEXT chunk's operands, in flight while this one is applied
         auto fetch = [&](int c0, int cn) {
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
-                const int e = tid + q * kBlock, col = e & (T - 1);
+                const int e = tid + q * kBlock, col = e & (kCols - 1);
                 const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;      // clamp: always a valid pair, used only if in range
                 tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
             }
@@ -1164,7 +1170,7 @@ void k_flush_mfma(const double *__restrict__ tiles, double *__restrict__ dst,
             __syncthreads();                                          // everyone is done with the previous chunk
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
-                const int e = tid + q * kBlock, i = e >> 7, col = e & (T - 1);
+                const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
                 if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
                 else if (i == cn) { Gs[2 * i][col] = 0.0; Gs[2 * i + 1][col] = 0.0; }       // pad of an odd count
             }
@@ -1180,23 +1186,55 @@ void k_flush_mfma(const double *__restrict__ tiles, double *__restrict__ dst,
 #pragma unroll 2
             for (int ks = 0; ks < ksteps; ++ks) {
                 const double a = Ks[4 * ks + lr][wave * 16 + lc];
-                double2 b[4];
+                double2 b[kBP][kE / 2];
 #pragma unroll
-                for (int bp = 0; bp < 4; ++bp) b[bp] = *reinterpret_cast<const double2 *>(&Gs[4 * ks + lr][32 * bp + 2 * lc]);
+                for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
-                for (int bp = 0; bp < 4; ++bp) {
-                    acc[bp][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp].x, acc[bp][0], 0, 0, 0);
-                    acc[bp][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp].y, acc[bp][1], 0, 0, 0);
-                }
+                    for (int h = 0; h < kE / 2; ++h)
+                        b[bp][h] = *reinterpret_cast<const double2 *>(&Gs[4 * ks + lr][16 * kE * bp + kE * lc + 2 * h]);
+#pragma unroll
+                for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+                    for (int h = 0; h < kE / 2; ++h) {
+                        acc[bp][2 * h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].x, acc[bp][2 * h], 0, 0, 0);
+                        acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
+                    }
             }
         }
 #pragma unroll
-        for (int bp = 0; bp < 4; ++bp)
+        for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                __builtin_nontemporal_store(acc[bp][0][r], td + (int64_t)(4 * r) * T + 32 * bp);
-                __builtin_nontemporal_store(acc[bp][1][r], td + (int64_t)(4 * r) * T + 32 * bp + 1);
-            }
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < kE; ++e)
+                    __builtin_nontemporal_store((TS)acc[bp][e][r], td + (int64_t)(4 * r) * T + 16 * kE * bp + e);
+    }
+}
+
+// the MFMA flush for the (storage type, tile edge) pairs it exists for; false: not applicable, use the VALU kernels
+template <typename TS, int T>
+static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_xcd, int64_t xcd_len, int pstart, int npairs,
+                              int grid_cap, hipStream_t s) {
+    constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
+    if constexpr (kHave) {
+        static const bool use_mfma = [] { const char *v = getenv("EKF_FLUSH_MFMA"); return !v || atoi(v) != 0; }();
+        static const int chunk_switch = [] { const char *v = getenv("EKF_FLUSH_MFMA_SWITCH"); return v ? atoi(v) : 26; }();
+        // F32 tiles: also for a single pair -- the 64 x 128 work items stream the float tiles faster than the one-pair VALU kernel
+        // (40 k landmarks: 4.4 ms vs 4.9 ms per pass); F64 tiles: the one-pair VALU kernel is the faster one (0.53 vs 0.56 ms)
+        constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;
+        if (!use_mfma || npairs < kMinPairs || !work_xcd || xcd_len <= 0) return false;
+        constexpr int kSubs = (T / 64) * (T / 128);
+        int64_t grid = 8 * xcd_len * kSubs;
+        if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+        if (npairs <= chunk_switch)
+            hipLaunchKernelGGL((k_flush_mfma<TS, T, 4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        else
+            hipLaunchKernelGGL((k_flush_mfma<TS, T, 8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        return true;
+    } else {
+        return false;
     }
 }
 
@@ -1205,22 +1243,10 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
                                      int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
+    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s)) return hipGetLastError();
     if constexpr (kLanes == 64 || kLanes == 32) {
         static const bool use_lds = [] { const char *v = getenv("EKF_FLUSH_LDS"); return !v || atoi(v) != 0; }();
         if constexpr (sizeof(TS) == 8 && T == 128 && kSlab == 32) {
-            static const bool use_mfma = [] { const char *v = getenv("EKF_FLUSH_MFMA"); return !v || atoi(v) != 0; }();
-            if (npairs > 1 && use_xcd && use_mfma && work_xcd && xcd_len > 0) {
-                int64_t grid = 8 * xcd_len * 2;
-                if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-                static const int chunk_switch = [] { const char *v = getenv("EKF_FLUSH_MFMA_SWITCH"); return v ? atoi(v) : 26; }();
-                if (npairs <= chunk_switch)
-                    hipLaunchKernelGGL((k_flush_mfma<4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
-                                       work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
-                else
-                    hipLaunchKernelGGL((k_flush_mfma<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
-                                       work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
-                return hipGetLastError();
-            }
             if (npairs > 1 && use_xcd && use_lds && work_xcd && xcd_len > 0) {
                 int64_t grid = 8 * xcd_len * 4;
                 if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;

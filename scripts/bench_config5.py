@@ -83,7 +83,7 @@ def main():
                       "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
                       "bulk_load_s": t_load, "state_finite": finite},
            "roofline": {"bound": "hbm", "achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": "k_downdate_w",
+                        "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": "k_flush_mfma<float,256>",
                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
                         "update_steps_per_launch": args.steps / max(launches, 1)}}
     print(json.dumps(out), flush=True)

@@ -203,3 +203,43 @@ def test_mfma_flush_equals_immediate_bitwise(batch):
     assert Pd.tobytes() == Pi.tobytes()             # signed zeros too
     np.testing.assert_array_equal(dfr.get_x(), imm.get_x())
     np.testing.assert_allclose(dfr.digest(), imm.digest(), rtol=1e-13)      # the digest's reduction order is not fixed
+
+
+_FLUSH_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from ekf_slam_amd import Engine
+storage, tile, batch, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+N = 300
+rng = np.random.default_rng(71)
+n = 3 + 2 * N
+x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N)])
+U = rng.normal(0, 0.05, size=(n, 6))
+P = np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T
+e = Engine(capacity=N, tile=tile, storage=storage, batch=batch)
+e.set_state(x, P, np.arange(1, N + 1.0))
+for step in range(2 * batch + 3):
+    e.predict([0.1, 2.0])
+    z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+    e.correct(z, np.diag([z[0] * .01, z[1] * 5.0]), int(rng.integers(0, N)))
+np.save(out, e.get_P())
+"""
+
+
+@pytest.mark.parametrize("storage,tile,batch", [("f32", 256, 5), ("f32", 256, 12), ("f32", 256, 33), ("f64", 128, 33)])
+def test_mfma_flush_equals_valu_flush_bitwise(tmp_path, storage, tile, batch):
+    """The matrix-core flush against the VALU flush it replaces (EKF_FLUSH_MFMA=0, read once per process -> child processes).
+    With F32 tiles a deferred run is not bit-equal to an immediate one (the tiles are rounded to float once per flush, not
+    once per correction), so this is the bitwise check for the F32 instance: same f64 FMA chain, same single rounding."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("P_%s.npy" % flag))
+        env = dict(os.environ, EKF_FLUSH_MFMA=flag)
+        r = subprocess.run([sys.executable, "-c", _FLUSH_CHILD, root, storage, str(tile), str(batch), out], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all()
+    assert outs[0].tobytes() == outs[1].tobytes()
