@@ -665,8 +665,9 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     h->cfg.batch = h->batch;
     h->st.pair_stride = 2 * ldm;
     h->st.pcap = h->async_flush ? 2 * h->batch : h->batch;      // in-flight batch + the batch being recorded
-    HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap));
-    HIPCHK(h, dalloc(h, &h->st.Kp, (size_t)(2 * ldm) * h->st.pcap));
+    // ONE allocation, G pairs then K pairs: k_gather addresses both from one uniform base with 32-bit lane offsets
+    HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap * 2));
+    h->st.Kp = h->st.Gp + (size_t)(2 * ldm) * h->st.pcap;
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
     HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));

@@ -19,8 +19,8 @@ struct DevState {
     // hold P_base; the live landmark block is P_base - sum_i K_i G_i (applied in slot order).
     // The slots form a ring of `pcap` entries: a kernel that is told (pstart, npend) sees the pairs in slots
     // (pstart + i) mod pcap, i = 0 .. npend-1, oldest first.
-    double *Gp;
-    double *Kp;
+    double *Gp;           // pending G pairs, then (same allocation) ...
+    double *Kp;           // ... the pending K pairs: Kp = Gp + pcap * pair_stride (k_gather relies on a 32-bit offset between them)
     int64_t pair_stride;   // 2 * ldm
     int32_t pcap;          // slots in the ring
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)

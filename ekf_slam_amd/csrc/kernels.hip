@@ -33,6 +33,21 @@ __device__ __forceinline__ double pmm_low(const TS *__restrict__ tiles, const Ti
     return (double)tiles[tm.tile_offset(I, J) + ((r & m) << tm.shift) + (c & m)];
 }
 
+template <typename TS> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+// canonical elements (r,c) and (r,c+1) for r > c + 1 and even c: adjacent in one tile row -> one 16- / 8-byte load
+template <typename TS>
+__device__ __forceinline__ void pmm_low_pair(const TS *__restrict__ tiles, const TileMap &tm, int64_t r, int64_t c, double &v0,
+                                             double &v1) {
+    const int64_t I = r >> tm.shift, J = c >> tm.shift;
+    const int64_t m = tm.T - 1;
+    const typename Vec2<TS>::type t =
+        *reinterpret_cast<const typename Vec2<TS>::type *>(tiles + tm.tile_offset(I, J) + ((r & m) << tm.shift) + (c & m));
+    v0 = (double)t.x; v1 = (double)t.y;
+}
+
 template <typename TS>
 __device__ __forceinline__ void pmm_low_store(TS *__restrict__ tiles, const TileMap &tm, int64_t r, int64_t c, double v) {
     if (r < c) { const int64_t t = r; r = c; c = t; }
@@ -332,8 +347,9 @@ struct PanelView {
     int32_t patched;    // 1: the pending pairs are already applied (k_rowpanel did it); 0: base values, patch here
     __device__ __forceinline__ double2 at(const TileMap &tm, int64_t c) const {
         const int64_t k = c >> tm.shift;
-        const int64_t o = (Ij + k) % tm.world;
-        const int64_t e = o * slab + offset + (((k / tm.world) << tm.shift) + (c & (tm.T - 1))) * 2;
+        const uint32_t wd = (uint32_t)tm.world;                      // 32-bit unsigned: see layout.h
+        const int64_t o = (uint32_t)(Ij + k) % wd;
+        const int64_t e = o * slab + offset + ((((int64_t)((uint32_t)k / wd)) << tm.shift) + (c & (tm.T - 1))) * 2;
         return make_double2(recv[e], recv[e + 1]);
     }
 };
@@ -357,7 +373,8 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // local column: kl * T + cc
     if (e >= (nchunks_local << tm.shift)) return;
     const int64_t Ij = j >> tm.shift;
-    const int64_t k0 = ((tm.rank - Ij) % tm.world + tm.world) % tm.world;   // first chunk owned by this shard
+    const uint32_t wd = (uint32_t)tm.world;
+    const int64_t k0 = ((uint32_t)tm.rank + wd - (uint32_t)Ij % wd) % wd;   // first chunk owned by this shard
     const int64_t kl = e >> tm.shift, cc = e & (tm.T - 1);
     const int64_t c = ((k0 + kl * tm.world) << tm.shift) + cc;
     double m0 = 0.0, m1 = 0.0;
@@ -410,43 +427,100 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 
     const bool do_patch = !kSharded || !pv.patched;       // base values in hand: apply the pending pairs here
     const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
+#ifdef EKF_GATHER_STAMPS
+    long long stamp[12]; int nst = 0;
+#define EKF_STAMP() do { stamp[nst++] = clock64(); } while (0)
+    EKF_STAMP();
+#else
+#define EKF_STAMP() do { } while (0)
+#endif
     const bool live = c < a.n_mm;
 
-    // (1) everything this column needs from memory is requested FIRST, so that it arrives while lane 0 runs the scalar
-    //     prologue below: the two landmark rows at column c (canonical lower-triangle entries: row part left of j,
-    //     column part right of j+1; from the tiles or from the exchanged row-panel), the strip column, x(c)
-    double m0 = 0.0, m1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, xc = 0.0;
-    if (live) {
-        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
-        else if (c <= j) { m0 = pmm_low<TS>(tiles, st.tm, j, c); m1 = pmm_low<TS>(tiles, st.tm, j + 1, c); }
-        else if (c >= j + 2) { m0 = pmm_low<TS>(tiles, st.tm, c, j); m1 = pmm_low<TS>(tiles, st.tm, c, j + 1); }
-        else { m0 = pmm_low<TS>(tiles, st.tm, j + 1, j); m1 = pmm_low<TS>(tiles, st.tm, j + 1, j + 1); }   // c == j + 1
-        s0 = strip[c]; s1 = strip[ldm + c]; s2 = strip[2 * ldm + c];
-        xc = x[3 + c];
-    }
-
-    // (2) the 5x5 sub-block P(S,S), the pose and the landmark, plus the wave-uniform operands of the pending pairs
-    if (tid < 9) pss[tid] = st.prr[cur][tid];
-    else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; pss[tid] = strip[t * ldm + j + b]; }
-    else if (tid < 19) {
+    // (1) Loads, in the order their consumers need them.  Vector-memory results return in order, so what gates the scalar
+    //     prologue is requested FIRST: the 5x5 sub-block P(S,S), the pose, the landmark (24 doubles, one per thread) and the
+    //     wave-uniform operands of the pending pairs (K_i / G_i at rows / columns j, j+1).
+    //     Every load below is unconditional with a selected / clamped address: a predicated load is merged by the compiler
+    //     with the predicated LDS write that consumes it, which puts a full memory round trip in front of everything else.
+    const double *sp = st.prr[cur];                              // threads >= 24 re-read Prr(1,1), unused
+    if (tid < 9) sp = st.prr[cur] + tid;
+    else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; sp = strip + t * ldm + j + b; }
+    else if (tid >= 19 && tid < 22) sp = x + (tid - 19);
+    else if (tid >= 22 && tid < 24) sp = x + 3 + j + (tid - 22);
+    double small_v = *sp;
+    if (tid >= 15 && tid < 19) {
         const int t = (tid - 15) >> 1, b = (tid - 15) & 1;     // canonical P(j+t, j+b)
         if (kSharded) {
             const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
-            pss[tid] = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
+            small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
         } else {
-            pss[tid] = pmm_low<TS>(tiles, st.tm, j + t, j + b);
+            // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
+            const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
+            const int rr = t > b ? t : b, cc2 = t > b ? b : t;
+            small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
         }
     }
-    else if (tid < 22) pss[tid] = x[tid - 19];
-    else if (tid < 24) pss[tid] = x[3 + j + (tid - 22)];
-    if (do_patch) {
-        for (int e = tid; e < 4 * npend; e += kBlock) {
-            const int i = e >> 2, which = e & 3;
-            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
-            upatch[e] = reinterpret_cast<const double2 *>(base)[j + (which & 1)];
+    static_assert(kMaxPending * 4 == 2 * kBlock, "two uniform operands per thread");
+    auto load_up = [&](int e0) {
+        const int e = (do_patch && e0 < 4 * npend) ? e0 : 0;     // clamped: slot pstart always exists
+        const int i = e >> 2, which = e & 3;
+        const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
+        return reinterpret_cast<const double2 *>(base)[j + (which & 1)];
+    };
+    const double2 up0 = load_up(tid), up1 = load_up(tid + kBlock);
+    __builtin_amdgcn_sched_barrier(0);      // keep these loads AHEAD of the per-column ones below (in-order return)
+    EKF_STAMP();                                                  // a: uniform operands requested
+    //     Then what this column needs: the two landmark rows at column c (canonical lower-triangle entries: row part left of
+    //     j, column part right of j+1 -- one 16-byte load there, j is even; from the tiles or from the exchanged row-panel),
+    //     the strip column, x(c) ...
+    double m0 = 0.0, m1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0, xc = 0.0;
+    const bool rowpart = c <= j, colpart = c >= j + 2;
+    if (live) {
+        if (kSharded) { const double2 m = pv.at(st.tm, c); m0 = m.x; m1 = m.y; }
+        else if (rowpart) {                                     // P(j, c), P(j+1, c): one tile (j is even), rows T apart
+            const int64_t m = st.tm.T - 1;
+            const TS *__restrict__ tp = tiles + st.tm.tile_offset(j >> st.tm.shift, c >> st.tm.shift) + ((j & m) << st.tm.shift) + (c & m);
+            m0 = (double)tp[0]; m1 = (double)tp[st.tm.T];
+        }
+        else if (colpart) pmm_low_pair<TS>(tiles, st.tm, c, j, m0, m1);
+        else pmm_low_pair<TS>(tiles, st.tm, j + 1, j, m0, m1);  // c == j + 1: canonical (j+1, j), (j+1, j+1)
+        s0 = strip[c]; s1 = strip[ldm + c]; s2 = strip[2 * ldm + c];
+        xc = x[3 + c];
+    }
+    //     ... and this column's operands of the first kPre pending pairs (G_i(:,c) left of j, K_i(c,:) right of it), all in
+    //     flight together: they used to be fetched 8 at a time inside the patch loop, one L2 round trip per 8 pairs
+    //     (0.17 us per pending pair, scripts/probe_gather_phases.py).
+    constexpr int kPre = 32;
+    const int npre = do_patch ? (npend < kPre ? npend : kPre) : 0;
+    const int64_t pad_cols = st.tm.padded(a.n_mm);
+    const int64_t ps2 = st.pair_stride / 2;
+    double2 pre[kPre];
+    {
+        // unconditional, clamped addresses (a predicated form lets the compiler sink the loads below the barrier, next to their
+        // use); slots past npend repeat the last pending one (cache hits), c is clamped into the padded vector
+        // One uniform base (Gp; Kp follows it in the same allocation, abi.hip) + a 32-bit per-lane element offset: the
+        // compiler can then use the scalar-base addressing form and the 32 loads cost one scalar add each.
+        const uint32_t cc = (uint32_t)(c < pad_cols ? c : pad_cols - 1);
+        const uint32_t krel = (uint32_t)((st.Kp - st.Gp) >> 1);
+        const uint32_t lane_off = cc + (rowpart ? 0u : krel);
+        const char *__restrict__ ub = reinterpret_cast<const char *>(st.Gp);
+        const uint32_t lane_bytes = lane_off * 16u;              // < 2^32: see below
+        // slot offsets advance incrementally around the ring (scalar unit: one add, one wrap test per pair)
+        // (32-bit: 2 * pcap * pair_stride / 2 <= 256 * 2 * capacity elements of 16 bytes stays far below 2^32)
+        const uint32_t step = (uint32_t)ps2, wrap = (uint32_t)st.pcap * step;
+        uint32_t off = (uint32_t)pstart * step;
+#pragma unroll
+        for (int i = 0; i < kPre; ++i) {
+            pre[i] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + lane_bytes);
+            if (i + 1 < npre) { off += step; if (off == wrap) off = 0; }
         }
     }
+
+    EKF_STAMP();                                                  // b: all loads requested
+    // (2) stage the uniform operands (waits for the FIRST group of loads only)
+    if (tid < 24) pss[tid] = small_v;
+    upatch[tid] = up0; upatch[tid + kBlock] = up1;                // unconditional too (entries past 4*npend are never read)
     __syncthreads();
+    EKF_STAMP();                                                  // 1: small operands staged
 
     // (3) the scalar prologue, spread over three wavefronts so that its independent pieces run side by side (they are
     //     long chains of dependent f64 operations on ONE lane each: ~5 us when done back to back):
@@ -459,22 +533,41 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         if (tid == 0) sincosd_ni(pss[21], stage[0], stage[1]);
         if (tid == 64) sincosd_ni(pss[21] + pa.u1, stage[2], stage[3]);
     }
-    if (do_patch && tid == 128) {
-        // canonical (j,j), (j+1,j), (j+1,j+1); operands are the staged ones
-        double d00 = pss[15], d10 = pss[17], d11 = pss[18];
-        for (int i = 0; i < npend; ++i) {
-            d00 = rank2_apply(d00, upatch[4 * i + 0], upatch[4 * i + 2]);
-            d10 = rank2_apply(d10, upatch[4 * i + 1], upatch[4 * i + 2]);
-            d11 = rank2_apply(d11, upatch[4 * i + 1], upatch[4 * i + 3]);
+    if (do_patch && tid >= 128 && tid < 131) {
+        // canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so that
+        // the LDS latency is paid per group, not per pair (it was 200 clocks per pending pair on one lane)
+        const int q = tid - 128;
+        const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
+        double d = pss[q == 0 ? 15 : q == 1 ? 17 : 18];
+        for (int i0 = 0; i0 < npend; i0 += 8) {
+            double2 kk[8], gg[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int ii = i0 + t < npend ? i0 + t : npend - 1;       // clamp: stay inside the staged entries
+                kk[t] = upatch[4 * ii + ka]; gg[t] = upatch[4 * ii + ga];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double v = rank2_apply(d, kk[t], gg[t]); d = i0 + t < npend ? v : d; }
         }
-        pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
+        if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
     }
     if (live && do_patch) {
-        const int64_t ps2 = st.pair_stride / 2;
-        if (c <= j) {
-            // pending pairs in chunks of 8: the 8 (independent) loads are issued together, then applied in order
+        if (rowpart) {
+#pragma unroll
+            for (int g0 = 0; g0 < kPre; g0 += 8)
+                if (g0 < npre) {                                  // uniform; inside a group no branches: select
+                    double2 ua[8], ub[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { ua[t] = upatch[4 * (g0 + t) + 0]; ub[t] = upatch[4 * (g0 + t) + 1]; }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const double v0 = rank2_apply(m0, ua[t], pre[g0 + t]), v1 = rank2_apply(m1, ub[t], pre[g0 + t]);
+                        m0 = g0 + t < npre ? v0 : m0; m1 = g0 + t < npre ? v1 : m1;
+                    }
+                }
+            // more than kPre pending pairs (async flush, batch > kPre): chunks of 8 independent loads, applied in order
             const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
-            int i = 0;
+            int i = npre;
             for (; i + 8 <= npend; i += 8) {
                 double2 g[8];
 #pragma unroll
@@ -490,9 +583,21 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
                 m0 = rank2_apply(m0, upatch[4 * i + 0], g);
                 m1 = rank2_apply(m1, upatch[4 * i + 1], g);
             }
-        } else if (c >= j + 2) {
+        } else if (colpart) {
+#pragma unroll
+            for (int g0 = 0; g0 < kPre; g0 += 8)
+                if (g0 < npre) {
+                    double2 ua[8], ub[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) { ua[t] = upatch[4 * (g0 + t) + 2]; ub[t] = upatch[4 * (g0 + t) + 3]; }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const double v0 = rank2_apply(m0, pre[g0 + t], ua[t]), v1 = rank2_apply(m1, pre[g0 + t], ub[t]);
+                        m0 = g0 + t < npre ? v0 : m0; m1 = g0 + t < npre ? v1 : m1;
+                    }
+                }
             const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
-            int i = 0;
+            int i = npre;
             for (; i + 8 <= npend; i += 8) {
                 double2 k[8];
 #pragma unroll
@@ -516,6 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         }
     }
     __syncthreads();
+    EKF_STAMP();                                                  // 2: sincos + patches done
     if (tid == 0 && kPredict) {
         // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
         const double pose[3] = { pss[19], pss[20], pss[21] };
@@ -525,14 +631,17 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         for (int i = 0; i < 3; ++i) pss[19 + i] = ps.pose[i];
     }
     if (kPredict) __syncthreads();
+    EKF_STAMP();                                                  // 3: predict finished
     if (tid == 0) solve_hs(pss[22] - pss[19], pss[23] - pss[20], stage[4], sol.Hs);   // EKF_SLAM.m:125-127,137-138
     if (tid == 64) stage[5] = bearing_ni(pss[23] - pss[20], pss[22] - pss[19], pss[21]);
     __syncthreads();
+    EKF_STAMP();                                                  // 4: H_s, atan2
     if (tid == 0) solve_rest(pss, stage[4], stage[5], a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
     __syncthreads();
+    EKF_STAMP();                                                  // 5: solve
 
     // (4) the column's share of G, K, x and the strip
-    const int64_t pad_end = ekf_tiles_for(a.n_mm, st.tm.T) << st.tm.shift;
+    const int64_t pad_end = st.tm.padded(a.n_mm);
     const int64_t out_off = (int64_t)ring_slot(pstart, npend, st.pcap) * st.pair_stride;   // this correction's own pair
     double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + out_off);
     double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + out_off);
@@ -555,15 +664,24 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
     }
-    if (c == 0) {
-        for (int b = 0; b < 3; ++b)
-            st.x[nxt][b] = pss[19 + b] + (sol.Kr[b][0] * sol.nu[0] + sol.Kr[b][1] * sol.nu[1]);   // x(3) NOT re-wrapped
-        for (int r = 0; r < 3; ++r) for (int b = 0; b < 3; ++b)
+    if (blockIdx.x == 0 && tid < 33) {
+        // the replicated small outputs, one entry per lane of workgroup 0 (they used to be ~35 dependent stores on one lane
+        // at the tail of the kernel): x_r (x(3) NOT re-wrapped), Prr, and G_r / K_r / Q for the host-side getters
+        if (tid < 3) st.x[nxt][tid] = pss[19 + tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
+        else if (tid < 12) {
+            const int r = (tid - 3) / 3, b = (tid - 3) - 3 * r;
             st.prr[nxt][3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
-        for (int r = 0; r < 2; ++r) for (int b = 0; b < 3; ++b) st.small[3 * r + b] = sol.Gr[r][b];
-        for (int b = 0; b < 3; ++b) for (int r = 0; r < 2; ++r) st.small[6 + 2 * b + r] = sol.Kr[b][r];
-        if (kPredict) for (int i = 0; i < 9; ++i) st.small[12 + i] = ps.Q[i];
+        }
+        else if (tid < 18) { const int r = (tid - 12) / 3, b = (tid - 12) - 3 * r; st.small[3 * r + b] = sol.Gr[r][b]; }
+        else if (tid < 24) { const int b = (tid - 18) >> 1, r = (tid - 18) & 1; st.small[6 + 2 * b + r] = sol.Kr[b][r]; }
+        else if (kPredict) st.small[12 + (tid - 24)] = ps.Q[tid - 24];
     }
+#ifdef EKF_GATHER_STAMPS
+    EKF_STAMP();                                                  // 6: outputs issued
+    __syncthreads();
+    if (c == 0) for (int i = 0; i < 9; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
+#endif
+#undef EKF_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -574,10 +692,6 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 // tile.  Inside it each lane owns one 16-byte column pair, so every wavefront load/store instruction moves
 // 1 KiB of contiguous tile memory; the lane's four G values and the row's two K values come from L2.
 // ---------------------------------------------------------------------------------------------------
-template <typename TS> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<float> { using type = float2; };
-
 template <typename TS, int T, int kSlab>
 __global__ __launch_bounds__(kBlock) void k_downdate(const TS *__restrict__ tiles, TS *__restrict__ dst,
                                                      const int2 *__restrict__ work, int64_t nwork,

@@ -29,15 +29,22 @@ struct TileMap {
     int32_t world;   // shards
     int32_t rank;    // this shard
 
+    // Tile indices are small non-negative numbers: all index arithmetic is 32-bit unsigned (a 64-bit integer division is
+    // a ~100-instruction sequence on the GPU and these run in the latency-critical prologue of every gather), and a single
+    // shard takes the division-free path.
     // number of local slots in tile rows [0, I)
     EKF_HD int64_t row_base(int64_t I) const {
-        const int64_t a = I / world, b = I % world;
-        return (int64_t)world * a * (a + 1) / 2 + b * (a + 1);
+        if (world == 1) return (I * (I + 1)) >> 1;
+        const uint32_t a = (uint32_t)I / (uint32_t)world, b = (uint32_t)I - a * (uint32_t)world;
+        return (((int64_t)world * a * (a + 1)) >> 1) + (int64_t)b * (a + 1);
     }
-    EKF_HD int32_t owner(int64_t I, int64_t J) const { return (int32_t)((I + J) % world); }
+    EKF_HD int32_t owner(int64_t I, int64_t J) const { return world == 1 ? 0 : (int32_t)((uint32_t)(I + J) % (uint32_t)world); }
     EKF_HD bool mine(int64_t I, int64_t J) const { return owner(I, J) == rank; }
     // local slot of tile (I,J), I >= J, valid only if mine(I,J)
-    EKF_HD int64_t slot(int64_t I, int64_t J) const { return row_base(I) + J / world; }
+    EKF_HD int64_t slot(int64_t I, int64_t J) const { return row_base(I) + (world == 1 ? J : (int64_t)((uint32_t)J / (uint32_t)world)); }
+    // tile rows covering m landmark-block rows; the same rounded up to whole tiles
+    EKF_HD int64_t tiles_for(int64_t mm_rows) const { return (mm_rows + T - 1) >> shift; }
+    EKF_HD int64_t padded(int64_t mm_rows) const { return tiles_for(mm_rows) << shift; }
     // element offset of tile (I,J) in the local tile store
     EKF_HD int64_t tile_offset(int64_t I, int64_t J) const { return slot(I, J) * (int64_t)T * T; }
     // local slots needed for nt tile rows
