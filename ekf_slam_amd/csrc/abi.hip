@@ -652,9 +652,32 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
             HIPCHK(h, dalloc(h, &tiles2, (size_t)slots * T * T * elt_size(h)));
             h->tilebuf[1] = tiles2;
             {
-                int lo = 0, hi = 0;
-                HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(h, hipStreamCreateWithPriority(&h->flush_stream, hipStreamNonBlocking, lo));
+                // The pass over P fills every CU (3 wavefronts x 146 VGPRs per SIMD); a gather launched meanwhile then waits for
+                // workgroup slots -- measured 20 us per gather, stream priorities do not help (profiles/round1_tuning.md, sweep
+                // 12).  So the flush stream is confined to a CU mask that leaves `reserve` CUs (default 32 = 4 per XCD) to the
+                // gather chain.  Reserved set {32a + 8b + a}: 4 CUs on every XCD whether mask bits map to XCDs round-robin
+                // (bit % 8) or in blocks of 32.  EKF_ASYNC_RESERVE_CUS=0: plain lowest-priority stream.
+                const char *rv = getenv("EKF_ASYNC_RESERVE_CUS");
+                int reserve = rv ? atoi(rv) : 32;
+                hipDeviceProp_t prop;
+                HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
+                const int ncu = prop.multiProcessorCount;
+                if (reserve > 0 && ncu == 256) {
+                    if (reserve > 128) reserve = 128;
+                    uint32_t mask[8];
+                    for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
+                    int taken = 0;
+                    for (int b = 0; b < 16 && taken < reserve; ++b)           // b < 4: the balanced set above; then its shifts
+                        for (int a = 0; a < 8 && taken < reserve; ++a) {
+                            const int bit = 32 * a + 8 * (b & 3) + ((a + (b >> 2)) & 7);
+                            if (mask[bit >> 5] & (1u << (bit & 31))) { mask[bit >> 5] &= ~(1u << (bit & 31)); ++taken; }
+                        }
+                    HIPCHK(h, hipExtStreamCreateWithCUMask(&h->flush_stream, 8, mask));
+                } else {
+                    int lo = 0, hi = 0;
+                    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    HIPCHK(h, hipStreamCreateWithPriority(&h->flush_stream, hipStreamNonBlocking, lo));
+                }
             }
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_pairs, hipEventDisableTiming));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_flushed, hipEventDisableTiming));

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     //     ... and this column's operands of the first kPre pending pairs (G_i(:,c) left of j, K_i(c,:) right of it), all in
     //     flight together: they used to be fetched 8 at a time inside the patch loop, one L2 round trip per 8 pairs
     //     (0.17 us per pending pair, scripts/probe_gather_phases.py).
+    // 32 pairs: a 64-pair variant (344 VGPRs, one workgroup per CU) was slower under an asynchronous flush (tuning log, sweep 12)
     constexpr int kPre = 32;
     const int npre = do_patch ? (npend < kPre ? npend : kPre) : 0;
     const int64_t pad_cols = st.tm.padded(a.n_mm);
