@@ -71,7 +71,8 @@ typedef struct ekf_config {
     int32_t async_flush;         /* with batch > 1: run each pass over P on a second stream, from the current tile
                                     store into a second one (2x tile memory), while the next corrections go on
                                     reading the current store plus all pending pairs; stores swap at the next
-                                    batch boundary.  Same bits as async_flush = 0.                          */
+                                    batch boundary.  Same bits as async_flush = 0.  The second stream is confined
+                                    to a CU mask that leaves 32 CUs (EKF_ASYNC_RESERVE_CUS) to the corrections. */
     int32_t reserved[6];
 } ekf_config;
 
