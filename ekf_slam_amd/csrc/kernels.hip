@@ -383,20 +383,32 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
         if (c <= j) {
             m0 = pmm_low<TS>(tiles, tm, j, c);
             m1 = pmm_low<TS>(tiles, tm, j + 1, c);
+            // pending pairs 8 at a time: the 8 (independent) loads are in flight together, then applied in slot order
             const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + c;
-            for (int i = 0; i < npend; ++i) {
-                const double2 g = gp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
-                m0 = rank2_apply(m0, upatch[4 * i + 0], g);
-                m1 = rank2_apply(m1, upatch[4 * i + 1], g);
+            for (int i0 = 0; i0 < npend; i0 += 8) {
+                double2 g[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) g[q] = gp[(int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < npend) {
+                        m0 = rank2_apply(m0, upatch[4 * (i0 + q) + 0], g[q]);
+                        m1 = rank2_apply(m1, upatch[4 * (i0 + q) + 1], g[q]);
+                    }
             }
         } else if (c >= j + 2) {
-            m0 = pmm_low<TS>(tiles, tm, c, j);
-            m1 = pmm_low<TS>(tiles, tm, c, j + 1);
+            pmm_low_pair<TS>(tiles, tm, c, j, m0, m1);
             const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + c;
-            for (int i = 0; i < npend; ++i) {
-                const double2 k = kp[(int64_t)ring_slot(pstart, i, st.pcap) * ps2];
-                m0 = rank2_apply(m0, k, upatch[4 * i + 2]);
-                m1 = rank2_apply(m1, k, upatch[4 * i + 3]);
+            for (int i0 = 0; i0 < npend; i0 += 8) {
+                double2 k[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) k[q] = kp[(int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (i0 + q < npend) {
+                        m0 = rank2_apply(m0, k[q], upatch[4 * (i0 + q) + 2]);
+                        m1 = rank2_apply(m1, k[q], upatch[4 * (i0 + q) + 3]);
+                    }
             }
         } else {                                                   // c == j + 1: canonical (j+1,j) and (j+1,j+1)
             m0 = pmm_low<TS>(tiles, tm, j + 1, j);
@@ -418,9 +430,15 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     __shared__ PredictSmall ps;
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const int tid = threadIdx.x;
-    const int cur = a.cur, nxt = cur ^ 1;
-    const double *__restrict__ x = st.x[cur];
-    const double *__restrict__ strip = st.strip[cur];
+    const int cur = a.cur;
+    // double-buffered state: both pointers of a pair arrive with the first kernel-argument fetch and are SELECTED (indexing the
+    // by-value struct with `cur` makes the compiler fetch the pointer with a second, dependent scalar load)
+    const double *__restrict__ x = cur ? st.x[1] : st.x[0];
+    const double *__restrict__ strip = cur ? st.strip[1] : st.strip[0];
+    const double *__restrict__ prr_cur = cur ? st.prr[1] : st.prr[0];
+    double *__restrict__ x_nxt = cur ? st.x[0] : st.x[1];
+    double *__restrict__ strip_nxt = cur ? st.strip[0] : st.strip[1];
+    double *__restrict__ prr_nxt = cur ? st.prr[0] : st.prr[1];
     const TS *__restrict__ tiles = (const TS *)st.tiles;
     const int64_t j = a.j, ldm = st.ldm;
     const int npend = a.npend, pstart = a.pstart;
@@ -441,8 +459,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     //     wave-uniform operands of the pending pairs (K_i / G_i at rows / columns j, j+1).
     //     Every load below is unconditional with a selected / clamped address: a predicated load is merged by the compiler
     //     with the predicated LDS write that consumes it, which puts a full memory round trip in front of everything else.
-    const double *sp = st.prr[cur];                              // threads >= 24 re-read Prr(1,1), unused
-    if (tid < 9) sp = st.prr[cur] + tid;
+    const double *sp = prr_cur;                                  // threads >= 24 re-read Prr(1,1), unused
+    if (tid < 9) sp = prr_cur + tid;
     else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; sp = strip + t * ldm + j + b; }
     else if (tid >= 19 && tid < 22) sp = x + (tid - 19);
     else if (tid >= 22 && tid < 24) sp = x + 3 + j + (tid - 22);
@@ -623,21 +641,40 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     }
     __syncthreads();
     EKF_STAMP();                                                  // 2: sincos + patches done
-    if (tid == 0 && kPredict) {
-        // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
-        const double pose[3] = { pss[19], pss[20], pss[21] };
-        predict_finish(pose, pss, pa.u0, pa.u1, pa.C, stage[0], stage[1], stage[2], stage[3], ps);
-        for (int i = 0; i < 9; ++i) pss[i] = ps.prr[i];
-        for (int b = 0; b < 2; ++b) predict_strip(pss[9 + b], pss[11 + b], pss[13 + b], ps.fa, ps.fb);
-        for (int i = 0; i < 3; ++i) pss[19 + i] = ps.pose[i];
+    if (tid == 0) {
+        // One lane runs the rest of the scalar chain back to back on register copies: predict -> H_s -> bearing -> solve,
+        // ~400 dependent f64 operations = 4700 clocks (scripts/probe_gather_phases.py).  Three barrier-separated phases with
+        // the atan2 on a second wavefront took the same time (the barriers and LDS hops cost what the parallel atan2 saved);
+        // this form has two workgroup barriers less.  Only spreading the 2x5 / 3x3 products over lanes would shorten it.
+        double p[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) p[i] = pss[i];
+        // results are formed in registers and copied to LDS once (forming them in the LDS structs put an LDS round trip
+        // between dependent operations)
+        SmallSolve so;
+        if (kPredict) {
+            // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
+            PredictSmall po;
+            const double pose[3] = { p[19], p[20], p[21] };
+            predict_finish(pose, p, pa.u0, pa.u1, pa.C, stage[0], stage[1], stage[2], stage[3], po);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) p[i] = po.prr[i];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) predict_strip(p[9 + b], p[11 + b], p[13 + b], po.fa, po.fb);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[19 + i] = po.pose[i];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) pss[i] = p[i];             // the output lanes read Prr and the pose from here
+#pragma unroll
+            for (int i = 19; i < 22; ++i) pss[i] = p[i];
+            ps = po;
+        }
+        double sq;
+        solve_hs(p[22] - p[19], p[23] - p[20], sq, so.Hs);                                // EKF_SLAM.m:125-127,137-138
+        const double bearing = bearing_ni(p[23] - p[20], p[22] - p[19], p[21]);
+        solve_rest(p, sq, bearing, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, so);
+        sol = so;
     }
-    if (kPredict) __syncthreads();
-    EKF_STAMP();                                                  // 3: predict finished
-    if (tid == 0) solve_hs(pss[22] - pss[19], pss[23] - pss[20], stage[4], sol.Hs);   // EKF_SLAM.m:125-127,137-138
-    if (tid == 64) stage[5] = bearing_ni(pss[23] - pss[20], pss[22] - pss[19], pss[21]);
-    __syncthreads();
-    EKF_STAMP();                                                  // 4: H_s, atan2
-    if (tid == 0) solve_rest(pss, stage[4], stage[5], a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
     __syncthreads();
     EKF_STAMP();                                                  // 5: solve
 
@@ -655,8 +692,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
         Gout[c] = make_double2(g[0], g[1]);
         Kout[c] = make_double2(k0, k1);
-        st.x[nxt][3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
-        double *__restrict__ sn = st.strip[nxt];
+        x_nxt[3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
+        double *__restrict__ sn = strip_nxt;
         sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
         sn[ldm + c] = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
         sn[2 * ldm + c] = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
@@ -668,10 +705,10 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     if (blockIdx.x == 0 && tid < 33) {
         // the replicated small outputs, one entry per lane of workgroup 0 (they used to be ~35 dependent stores on one lane
         // at the tail of the kernel): x_r (x(3) NOT re-wrapped), Prr, and G_r / K_r / Q for the host-side getters
-        if (tid < 3) st.x[nxt][tid] = pss[19 + tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
+        if (tid < 3) x_nxt[tid] = pss[19 + tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
         else if (tid < 12) {
             const int r = (tid - 3) / 3, b = (tid - 3) - 3 * r;
-            st.prr[nxt][3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
+            prr_nxt[3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
         }
         else if (tid < 18) { const int r = (tid - 12) / 3, b = (tid - 12) - 3 * r; st.small[3 * r + b] = sol.Gr[r][b]; }
         else if (tid < 24) { const int b = (tid - 18) >> 1, r = (tid - 18) & 1; st.small[6 + 2 * b + r] = sol.Kr[b][r]; }

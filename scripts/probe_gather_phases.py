@@ -16,10 +16,10 @@ R = np.diag([0.2, 50.0])
 rows = []
 for i in range(3 * batch):
     e.predict([0.1, 3.0]); e.correct([10.0, 100.0], R, (i * 37) % N)
-    q = e.get_Q3().reshape(-1)[:9]          # stamps in shader clocks relative to kernel entry
+    q = e.get_Q3().reshape(-1)[:7]          # stamps in shader clocks relative to kernel entry
     if i >= batch:
         rows.append((i % batch, q))
-names = ["uniform loads issued", "all loads issued", "staged", "sincos+patch", "predict", "Hs/atan2", "solve", "outputs"]
+names = ["uniform loads issued", "all loads issued", "staged", "sincos+patch", "predict+Hs+atan2+solve", "outputs"]
 for lo, hi in ((0, 4), (batch // 2 - 2, batch // 2 + 2), (batch - 4, batch)):
     sel = np.array([q for (k, q) in rows if lo <= k < hi])
     dq = np.diff(sel, axis=1).mean(axis=0)
