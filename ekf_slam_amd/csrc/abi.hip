@@ -428,8 +428,7 @@ int32_t prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
     for (int32_t q = 0; q < m; ++q)
         REQUIRE(h, idx[q] >= 0 && idx[q] < h->N, EKF_ERR_INDEX, "prefetch: landmark index outside the state");
     const int64_t slab = slab_for(h, n_mm(h));
-    for (int32_t q = 0; q < m; ++q)
-        HIPCHK(h, launch_rowpanel(h->st, 2 * idx[q], n_mm(h), 0, /*npend*/ 0, h->send + (size_t)q * slab, h->storage, h->stream));
+    HIPCHK(h, launch_rowpanel_base(h->st, idx, m, n_mm(h), h->send, slab, h->storage, h->stream));
     h->pf_valid = false;
     h->pf_idx.assign(idx, idx + m);
     h->pf_m = m; h->pf_slab = slab; h->pf_N = h->N;

@@ -79,7 +79,12 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
 // sharded correction: (1) every shard copies the chunks of the landmark row-panel P(j:j+1,:) it owns into `send`
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
+struct RowList { int32_t m; int32_t j[64]; };      // landmark-block rows (2 * landmark index) of one prefetch
+
 int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
+// base row-panels of m <= 64 landmarks (0-based indices idx) into send + q * slab, one launch
+hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, int64_t n_mm, double *send, int64_t slab,
+                                int storage, hipStream_t s);
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
                            hipStream_t s);
 // recv: `world` contributions `rank_stride` doubles apart; this correction's row-panel starts `offset` doubles into

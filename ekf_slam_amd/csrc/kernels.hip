@@ -423,6 +423,33 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
 }
 
 
+// The BASE row-panels (no pending pairs applied) of up to 64 landmarks in ONE launch: blockIdx.y picks the landmark, the rest
+// is k_rowpanel with npend = 0.  A prefetch (ekf_prefetch_rows) used to launch k_rowpanel once per landmark: 32 launches of
+// ~3 us in front of every batch's all-gather.
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_rowpanel_base(DevState st, RowList rows, int64_t n_mm, double *__restrict__ send,
+                                                          int64_t slab) {
+    const TileMap &tm = st.tm;
+    const TS *__restrict__ tiles = (const TS *)st.tiles;
+    const int q = blockIdx.y;
+    const int64_t j = rows.j[q];
+    const uint32_t wd = (uint32_t)tm.world;
+    const uint32_t Ij = (uint32_t)(j >> tm.shift), nt = (uint32_t)tm.tiles_for(n_mm);
+    const uint32_t k0 = ((uint32_t)tm.rank + wd - Ij % wd) % wd;       // first chunk owned by this shard
+    const uint32_t nloc = k0 >= nt ? 0u : (nt - k0 + wd - 1) / wd;
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;      // local column: kl * T + cc
+    if (e >= ((int64_t)nloc << tm.shift)) return;
+    const int64_t kl = e >> tm.shift, cc = e & (tm.T - 1);
+    const int64_t c = (((int64_t)k0 + kl * tm.world) << tm.shift) + cc;
+    double m0 = 0.0, m1 = 0.0;
+    if (c < n_mm) {
+        if (c <= j) { m0 = pmm_low<TS>(tiles, tm, j, c); m1 = pmm_low<TS>(tiles, tm, j + 1, c); }
+        else if (c >= j + 2) pmm_low_pair<TS>(tiles, tm, c, j, m0, m1);
+        else pmm_low_pair<TS>(tiles, tm, j + 1, j, m0, m1);           // c == j + 1: canonical (j+1,j) and (j+1,j+1)
+    }
+    reinterpret_cast<double2 *>(send + (int64_t)q * slab)[e] = make_double2(m0, m1);
+}
+
 template <typename TS, bool kSharded, bool kPredict>
 __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
     __shared__ double pss[24];
@@ -1148,6 +1175,23 @@ hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int psta
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc),
         hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc));
+    return hipGetLastError();
+}
+
+hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, int64_t n_mm, double *send, int64_t slab,
+                                int storage, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    if (m > 64) return hipErrorInvalidValue;
+    RowList rows;
+    rows.m = m;
+    for (int q = 0; q < m; ++q) rows.j[q] = (int32_t)(2 * idx[q]);
+    const int64_t nt = st.tm.tiles_for(n_mm);
+    const int64_t max_chunks = (nt + st.tm.world - 1) / st.tm.world;
+    if (max_chunks == 0) return hipSuccess;
+    const int64_t grid = cdiv(max_chunks * st.tm.T, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_rowpanel_base<double>, dim3((unsigned)grid, (unsigned)m), dim3(kBlock), 0, s, st, rows, n_mm, send, slab),
+        hipLaunchKernelGGL(k_rowpanel_base<float>, dim3((unsigned)grid, (unsigned)m), dim3(kBlock), 0, s, st, rows, n_mm, send, slab));
     return hipGetLastError();
 }
 
