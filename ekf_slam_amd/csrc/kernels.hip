@@ -932,8 +932,34 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         // the 2x2 diagonal block lives in a diagonal tile; on another shard's tile the position cost is NaN
         // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
         const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
-        for (int t = 0; t < 2; ++t) for (int b = 0; b < 2; ++b)
-            pss[15 + 2 * t + b] = have_diag ? pmm_live<TS>(tiles, st, a.pstart, a.npend, j + t, j + b) : NAN;
+        if (have_diag) {
+            // live canonical (j,j), (j+1,j), (j+1,j+1): base values minus the pending pairs in slot order (= pmm_live), with
+            // the operands of 4 pairs (16 loads) in flight together instead of one dependent round trip per pair and entry
+            double d00, d10, d11;
+            d00 = pmm_low<TS>(tiles, st.tm, j, j);
+            pmm_low_pair<TS>(tiles, st.tm, j + 1, j, d10, d11);
+            const int64_t ps2 = st.pair_stride / 2;
+            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + j;
+            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + j;
+            for (int i0 = 0; i0 < a.npend; i0 += 4) {
+                double2 k0[4], k1[4], g0[4], g1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t so = (int64_t)ring_slot(a.pstart, i0 + q < a.npend ? i0 + q : a.npend - 1, st.pcap) * ps2;
+                    k0[q] = kp[so]; k1[q] = kp[so + 1]; g0[q] = gp[so]; g1[q] = gp[so + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (i0 + q < a.npend) {
+                        d00 = rank2_apply(d00, k0[q], g0[q]);
+                        d10 = rank2_apply(d10, k1[q], g0[q]);
+                        d11 = rank2_apply(d11, k1[q], g1[q]);
+                    }
+            }
+            pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
+        } else {
+            pss[15] = pss[16] = pss[17] = pss[18] = NAN;
+        }
         for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
         SmallSolve sol;
