@@ -105,8 +105,8 @@ def load_traffic(N, tile, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=320)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1280)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
     ap.add_argument("--batch", type=int, default=32,
