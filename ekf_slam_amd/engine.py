@@ -42,6 +42,7 @@ class Engine:
                 setattr(cfg, k, v)
         self.cfg = cfg
         self._host_exchange = None
+        self._raw = None
         self.h = ctypes.c_void_p()
         rc = self.lib.ekf_create(ctypes.byref(cfg), ctypes.byref(self.h))
         if rc != L.EKF_OK:
@@ -70,6 +71,44 @@ class Engine:
     # ---- hot path ----
     def predict(self, u):
         self._check(self.lib.ekf_predict(self.h, _p(_vec(u, 2))))
+
+    # ---- pre-marshalled inputs (hosts that stream many steps: bench.py) ----
+    # The plain methods convert their arguments on every call (numpy + ctypes: ~10 us per predict + correct in CPython, more
+    # than a shard of an 8-GPU run spends on the GPU per update-step).  `marshal_steps` lays a whole run out once in three
+    # contiguous arrays; `step_raw(i)` then issues predict + correct of step i with integer addresses only.
+    def marshal_steps(self, steps):
+        """steps: iterable of (u[2], z[2], R[2x2], idx0).  Returns an opaque run object for step_raw / prefetch use."""
+        steps = list(steps)
+        m = len(steps)
+        U = np.empty((m, 2)); Z = np.empty((m, 2)); Rm = np.empty((m, 4)); K = np.empty(m, dtype=np.int64)
+        for i, (u, z, R, k) in enumerate(steps):
+            U[i] = np.asarray(u, dtype=np.float64).reshape(-1)[:2]
+            Z[i] = np.asarray(z, dtype=np.float64).reshape(-1)[:2]
+            Rm[i] = np.asarray(R, dtype=np.float64).reshape(2, 2).reshape(-1, order="F")       # column-major, as the ABI takes it
+            K[i] = int(k)
+        if self._raw is None:
+            proto_p = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
+            proto_c = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+            self._raw = (proto_p(("ekf_predict", self.lib)), proto_c(("ekf_correct", self.lib)),
+                         proto_c(("ekf_correct_begin", self.lib)))
+        return {"U": U, "Z": Z, "R": Rm, "K": K, "k": K.tolist(), "u": U.ctypes.data, "z": Z.ctypes.data, "r": Rm.ctypes.data, "m": m}
+
+    def step_raw(self, run, i):
+        """predict(u_i) + correct(z_i, R_i, idx_i) of a marshalled run."""
+        f_pred, f_corr, f_begin = self._raw
+        rc = f_pred(self.h, run["u"] + 16 * i)
+        if rc:
+            self._check(rc)
+        if self._host_exchange is not None:
+            rc = f_begin(self.h, run["z"] + 16 * i, run["r"] + 32 * i, run["k"][i])
+            if rc:
+                self._check(rc)
+            self._host_exchange(self)
+            self.correct_finish()
+            return
+        rc = f_corr(self.h, run["z"] + 16 * i, run["r"] + 32 * i, run["k"][i])
+        if rc:
+            self._check(rc)
 
     def append(self, u, R, pos, signature):
         self._check(self.lib.ekf_append(self.h, _p(_vec(u, 2)), _p(_colmajor(R).reshape(-1, order="F")),

@@ -243,3 +243,26 @@ def test_mfma_flush_equals_valu_flush_bitwise(tmp_path, storage, tile, batch):
         outs.append(np.load(out))
     assert np.isfinite(outs[0]).all()
     assert outs[0].tobytes() == outs[1].tobytes()
+
+
+def test_marshalled_steps_equal_plain_calls():
+    """Engine.marshal_steps / step_raw (pre-marshalled inputs, integer addresses only) is the same sequence of ABI calls as
+    predict() + correct() with per-call conversion."""
+    from ekf_slam_amd import Engine
+    N = 150
+    x, P, s = _state(N, 67)
+    a = Engine(capacity=N, tile=64, batch=4)
+    b = Engine(capacity=N, tile=64, batch=4)
+    a.set_state(x, P, s); b.set_state(x, P, s)
+    rng = np.random.default_rng(4)
+    steps = []
+    for _ in range(19):
+        z = np.array([rng.uniform(1, 30), rng.uniform(1, 359)])
+        steps.append(([0.1, float(rng.uniform(-3, 3))], z, np.array([[z[0] * .01, 0.002], [0.002, z[1] * 5.0]]), int(rng.integers(0, N))))
+    for (u, z, R, k) in steps:
+        a.predict(u); a.correct(z, R, k)
+    run = b.marshal_steps(steps)
+    for i in range(run["m"]):
+        b.step_raw(run, i)
+    np.testing.assert_array_equal(a.get_x(), b.get_x())
+    np.testing.assert_array_equal(a.get_P(), b.get_P())
