@@ -554,10 +554,20 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         // (32-bit: 2 * pcap * pair_stride / 2 <= 256 * 2 * capacity elements of 16 bytes stays far below 2^32)
         const uint32_t step = (uint32_t)ps2, wrap = (uint32_t)st.pcap * step;
         uint32_t off = (uint32_t)pstart * step;
+        // Groups of 8 are skipped when no pending pair falls into them (immediate mode, the start of every batch).  The group
+        // test uses an OPAQUE copy of npre: with the same condition as at the use sites the compiler would merge each group
+        // of loads into the block that consumes it, below the barrier.
+        int npre_ld = npre;
+        asm volatile("" : "+s"(npre_ld));
 #pragma unroll
-        for (int i = 0; i < kPre; ++i) {
-            pre[i] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + lane_bytes);
-            if (i + 1 < npre) { off += step; if (off == wrap) off = 0; }
+        for (int g0 = 0; g0 < kPre; g0 += 8) {
+            if (g0 < npre_ld) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    pre[g0 + t] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + lane_bytes);
+                    if (g0 + t + 1 < npre) { off += step; if (off == wrap) off = 0; }
+                }
+            }
         }
     }
 
