@@ -1,5 +1,5 @@
 """k_gather under a concurrent flush (cfg.async_flush): phase stamps of the last gather of a burst + mean launch duration.
-Needs the -DEKF_GATHER_STAMPS library: EKF_LIB_PATH=.../stamps.so python scripts/probe_gather_async.py [landmarks] [batch]"""
+Needs the -DEKF_GATHER_STAMPS library: make -C ekf_slam_amd/csrc stamps && EKF_LIB_PATH=$PWD/ekf_slam_amd/libekfslam_stamps.so python scripts/probe_gather_async.py [landmarks] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

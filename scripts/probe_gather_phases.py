@@ -1,5 +1,5 @@
 """Where does a k_gather launch spend its time?  Needs a library built with -DEKF_GATHER_STAMPS (clock64() stamps of workgroup 0,
-returned through the Q slots): EKF_LIB_PATH=.../stamps.so python scripts/probe_gather_phases.py [landmarks] [batch]"""
+returned through the Q slots): make -C ekf_slam_amd/csrc stamps && EKF_LIB_PATH=$PWD/ekf_slam_amd/libekfslam_stamps.so python scripts/probe_gather_phases.py [landmarks] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
