@@ -80,6 +80,7 @@ struct ekf_handle {
     bool inflight = false;
     hipStream_t flush_stream = nullptr;
     hipEvent_t ev_pairs = nullptr, ev_flushed = nullptr;
+    hipEvent_t ev_xchg = nullptr;    // ekf_exchange_local: this shard's copies of one exchange are done
     // lazy predict: ekf_predict only records u; the next correction folds it into its gather kernel (one launch
     // instead of two, identical arithmetic); any other consumer of x / P launches k_predict first
     bool have_pp = false;
@@ -732,6 +733,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (hipEvent_t e : h->throttle_ev) if (e) hipEventDestroy(e);
     if (h->flush_stream) { hipStreamSynchronize(h->flush_stream); hipStreamDestroy(h->flush_stream); }
+    if (h->ev_xchg) hipEventDestroy(h->ev_xchg);
     if (h->ev_pairs) hipEventDestroy(h->ev_pairs);
     if (h->ev_flushed) hipEventDestroy(h->ev_flushed);
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
@@ -968,6 +970,16 @@ int32_t ekf_exchange_local(ekf_handle **hs, int32_t world) {
         for (int src = 0; src < world; ++src)
             HIPCHK(d, hipMemcpyPeerAsync(d->recv + (size_t)src * d->x_count, d->cfg.device, hs[src]->send,
                                          hs[src]->cfg.device, bytes, d->stream));
+        if (!d->ev_xchg) HIPCHK(d, hipEventCreateWithFlags(&d->ev_xchg, hipEventDisableTiming));
+        HIPCHK(d, hipEventRecord(d->ev_xchg, d->stream));
+    }
+    // consumers before the next producers: a shard's stream may run ahead into its next extract (k_rowpanel overwrites its
+    // send slab) while another shard's stream has not yet copied that slab -- every stream waits for every shard's copies.
+    // (Found as an intermittent divergence of the replicated state across a 4-shard group on one GPU.)
+    for (int r = 0; r < world; ++r) {
+        HIPCHK(hs[r], hipSetDevice(hs[r]->cfg.device));
+        for (int dst = 0; dst < world; ++dst)
+            if (dst != r) HIPCHK(hs[r], hipStreamWaitEvent(hs[r]->stream, hs[dst]->ev_xchg, 0));
     }
     return EKF_OK;
 }

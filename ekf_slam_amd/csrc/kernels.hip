@@ -470,6 +470,15 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     const int64_t j = a.j, ldm = st.ldm;
     const int npend = a.npend, pstart = a.pstart;
 
+    // Fetch every kernel argument this kernel uses NOW, in one burst of scalar loads: left to itself the compiler fetches
+    // them lazily, right before their first use, which put three dependent round trips to the argument block at the head of
+    // the kernel's critical path.
+    {
+        const double *t_tiles = (const double *)st.tiles;
+        asm volatile("" :: "s"(st.ldm), "s"(st.pair_stride), "s"(st.pcap), "s"(st.Gp), "s"(st.Kp), "s"(t_tiles), "s"(st.small),
+                     "s"(st.tm.T), "s"(st.tm.shift), "s"(st.tm.world), "s"(st.tm.rank), "s"(a.j), "s"(a.n_mm), "s"(a.npend),
+                     "s"(a.pstart));
+    }
     const bool do_patch = !kSharded || !pv.patched;       // base values in hand: apply the pending pairs here
     const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
 #ifdef EKF_GATHER_STAMPS
