@@ -232,7 +232,11 @@ def main():
     head = run_leg(args.batch, args.steps, args.warmup)
     look = None
     if world > 1 and args.batch > 1:
-        look = run_leg(args.batch, args.steps, args.warmup, lookahead=True)
+        try:
+            look = run_leg(args.batch, args.steps, args.warmup, lookahead=True)
+        except Exception as ex:  # noqa: BLE001 -- an argument / state error is raised identically on every rank: report, go on
+            print("[rank %d] lookahead leg failed: %s" % (rank, ex), file=sys.stderr, flush=True)
+            look = None
     imm = None
     if not args.no_immediate and args.batch > 1:
         n_imm = min(args.steps, 128)
