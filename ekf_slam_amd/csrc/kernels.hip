@@ -1,15 +1,17 @@
 // gfx950 (MI355X / CDNA4) kernels of the EKF-SLAM update engine.
 //
-// Every kernel here is HBM- or latency-bound (AI of the rank-2 downdate is 0.25 flop/B in f64); none is
-// GEMM-shaped, so the rules that matter are: 16-byte-per-lane coalesced accesses on whole 64-lane
-// wavefronts, many independent loads in flight per lane, >> 256 workgroups per launch, nothing re-read
-// from HBM that can be kept in registers, no host synchronisation between launches.
+// The path as the reference writes it is HBM- or latency-bound (AI of the rank-2 downdate is 0.25 flop/B in f64), so the
+// rules that matter are: 16-byte-per-lane coalesced accesses on whole 64-lane wavefronts, many independent loads in
+// flight per lane, >> 256 workgroups per launch, nothing re-read from HBM that can be kept in registers, no host
+// synchronisation between launches.  Two pieces ARE GEMM-shaped and run on the f64 matrix cores, bit-identical to
+// their scalar fma formulation: the deferred rank-2m flush (k_flush_mfma) and the predict panel (k_predict_mfma).
 //
 // Reference expressions realised (file:line in the reference tree):
 //   k_predict    P = F*P*F' + Q, x = f(x,u), wrapTo360          EKF_SLAM.m:40-51,56-65
 //   k_append     state/covariance growth                         EKF_SLAM.m:67-98 (append.m:1-27)
 //   k_gather     z_k, H_k, phi_k, K, x += K nu                   EKF_SLAM.m:125-144
-//   k_downdate   P = (I - K H_k) P  ==  P - K (H_k P)            EKF_SLAM.m:145
+//   k_downdate*  P = (I - K H_k) P  ==  P - K (H_k P)            EKF_SLAM.m:145
+//   k_flush_*    the same for m deferred corrections in one pass  EKF_SLAM.m:145 (x m)
 //   k_associate  per-landmark phi_k, Mahalanobis + signature     Correspondence.m:49-87
 #include "kernels.h"
 
@@ -588,12 +590,12 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     EKF_STAMP();                                                  // 1: small operands staged
 
     // (3) the scalar prologue, spread over three wavefronts so that its independent pieces run side by side (they are
-    //     long chains of dependent f64 operations on ONE lane each: ~5 us when done back to back):
+    //     long chains of dependent f64 operations on ONE lane each):
     //       wave 0: sind/cosd of the pre-motion heading      wave 1: sind/cosd of heading + u2
     //       wave 2: the pending pairs on the 2x2 diagonal block
-    //     then wave 0 finishes the predict and forms delta; then wave 0 does sqrt / H_s while wave 1 does the atan2;
-    //     then wave 0 finishes the solve.  Meanwhile every lane applies the pending pairs to its own two row entries.
-    __shared__ double stage[8];          // 0..3: sn, cs, sn2, cs2   4..5: sqrt(q), bearing
+    //     Meanwhile every lane applies the pending pairs to its own two row entries.  After the barrier lane 0 runs the
+    //     rest of the chain (predict, H_s, bearing, 2x2 solve) in one piece.
+    __shared__ double stage[4];          // sn, cs, sn2, cs2
     if (kPredict) {
         if (tid == 0) sincosd_ni(pss[21], stage[0], stage[1]);
         if (tid == 64) sincosd_ni(pss[21] + pa.u1, stage[2], stage[3]);
