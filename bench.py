@@ -102,6 +102,18 @@ def load_traffic(N, tile, batch):
     return None
 
 
+def load_matrix_pipe(N, tile, batch):
+    """Matrix-pipe utilisation of the batched flush from the committed PMC summary (profiles/round1_mfma_pmc.json: measured at
+    10 000 landmarks, tile 128, 32 pairs), or None for any other configuration."""
+    if (N, tile, batch) != (10000, 128, 32):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_mfma_pmc.json")) as fh:
+            return json.load(fh)["derived"]["mfma_pipe_utilisation"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,7 +237,9 @@ def main():
                 "traffic": load_traffic(N, args.tile, batch) if world == 1 else None,
                 "kernel": ("k_flush_mfma" if (batch > 1 and args.tile == 128) else "k_downdate_w" if args.tile >= 64 else "k_downdate"), "launches": launches,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg_rank,
-                "update_steps_per_launch": nsteps / max(launches, 1)}
+                "update_steps_per_launch": nsteps / max(launches, 1),
+                # f64 matrix-pipe busy fraction of this kernel (PMC, committed summary); null where it was not measured
+                "matrix_pipe_busy": load_matrix_pipe(N, args.tile, batch) if world == 1 else None}
         return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "roofline": roof, "transport": transport,
                 "state_finite": finite, "x_end": x_end, "digest": digest}
 
