@@ -7,18 +7,27 @@ D = diag(U(0.01,0.1)), U = n x 8 N(0,0.01^2)); one step = 1 predict + 1 correcti
 :124-145) on a cycling landmark index, with range/bearing taken from the world's true pose.  Inputs are
 resident in HBM before the timed region; the only per-step host->device traffic is kernel arguments.
 
-Two legs are measured in the same invocation:
-  * headline (`value`): the engine's deferred mode, cfg.batch = --batch: corrections are kept as pending
-    rank-2 pairs (every row a later correction reads is patched on the fly) and applied to P in ONE pass per
-    `batch` update-steps -- bit-identical results, 1/batch of the HBM traffic per update-step.  The timed
-    region ends with a flush, so every correction has been applied to every entry of P inside it.
-  * `immediate`: cfg.batch = 1, every correction rewrites P at once (EKF_SLAM.m:145 as written); this is the
-    leg whose downdate kernel is purely HBM-bound and is compared with the 8 TB/s roofline.
+Legs measured in one invocation (every leg carries its own algorithmic bytes per step, so bytes/step / ms/step <= HBM
+peak can be checked on each):
+  * HEADLINE (`value`, `ms_per_step`, `roofline`): the update-step AS WRITTEN -- cfg.batch = 1, every correction rewrites
+    P at once (EKF_SLAM.m:145 once per update-step): B_alg = w n (n+1) bytes per step, one k_downdate_w
+    launch per step, purely HBM-bound; this is the number to hold against the >= 60 % roofline target.
+  * `deferred`: the engine's deferred mode, cfg.batch = --batch: corrections are kept as pending rank-2
+    pairs (every row a later correction reads is patched on the fly) and applied to P in ONE pass per `batch`
+    update-steps -- bit-identical results, B_alg / batch + O(n) bytes per step.  The timed region ends with a flush, so
+    every correction has been applied to every entry of P inside it.
+  * N > 1 only, `deferred_lookahead`: the same with the next batch's landmarks announced (ekf_prefetch_rows): one
+    all-gather per batch instead of one per update-step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 32]
 
-For N > 1 launch one rank per GPU (torch.distributed.run); P is split over the ranks (tile (I,J) on rank
-(I+J) mod N) and each update-step carries one all-gather of the 2 x n landmark row-panel.
+N > 1: one process per GPU.  Started by an external launcher (RANK / WORLD_SIZE in the environment, e.g.
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) this process is one rank; started plainly as
+`python bench.py --gpus N` it spawns that launcher as a CHILD process before touching HIP or torch, relays rank 0's JSON
+line and exits non-zero if any rank failed.  P is split over the ranks (tile (I,J) on rank (I+J) mod N) and each
+update-step carries one RCCL all-gather of the 2 x 2N landmark row-panel on the library's own communicator
+(`config.transport` = "rccl-native"; a failed attach is an error, there is no second transport behind it).
+EKF_BENCH_BACKEND=gloo rehearses the multi-rank flow on ONE GPU (host-staged exchange, all ranks on device 0).
 
 Prints ONE JSON line on rank 0.
 """
@@ -88,30 +97,49 @@ def cpu_baseline(N, x, s, d, U, steps, budget_s=20.0):
                       "restatement with OpenMP (oracle/ekf_structured.c), full n x n P" % (done, N)}
 
 
-def load_traffic(N, tile, batch):
-    """HBM bytes per downdate launch from the committed PMC summary (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "downdate_pmc.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)
+def load_committed_pmc(N, tile, pairs):
+    """HBM bytes per downdate launch from the newest committed PMC summary (profiles/round*_downdate_pmc.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command) for exactly this launch shape, else None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_downdate_pmc.json")),
+                   key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
+    for path in reversed(files):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
         for leg in rec.get("legs", []):
-            if leg.get("landmarks") == N and leg.get("tile") == tile and leg.get("batch") == batch:
-                return leg.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+            if leg.get("landmarks") == N and leg.get("tile") == tile and leg.get("batch") == pairs:
+                return {"file": os.path.relpath(path, ROOT), "pairs_per_launch": pairs, "landmarks": N, "tile": tile,
+                        "kernel": leg.get("kernel"), "hbm_bytes_per_launch": leg.get("hbm_bytes_per_launch"),
+                        "matrix_pipe_busy": leg.get("matrix_pipe_busy")}
     return None
 
 
-def load_matrix_pipe(N, tile, batch):
-    """Matrix-pipe utilisation of the batched flush from the committed PMC summary (profiles/round1_mfma_pmc.json: measured at
-    10 000 landmarks, tile 128, 32 pairs), or None for any other configuration."""
-    if (N, tile, batch) != (10000, 128, 32):
-        return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_mfma_pmc.json")) as fh:
-            return json.load(fh)["derived"]["mfma_pipe_utilisation"]
-    except (OSError, ValueError, KeyError):
-        return None
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes.  Nothing in this
+    process has touched HIP or torch (never re-exec a process that initialised the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or not lines:
+        print("bench.py: the %d-rank run failed (launcher exit code %d)" % (args.gpus, proc.returncode), file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    sys.exit(0)
 
 
 def main():
@@ -122,23 +150,22 @@ def main():
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
     ap.add_argument("--batch", type=int, default=32,
-                    help="corrections per pass over P (headline leg); with the MFMA flush 32 keeps the pass at ~64 %% of the HBM "
-                         "roofline, 24 at ~70 %% with ~10 %% fewer update-steps/s (profiles/round1_tuning.md, sweep 10)")
+                    help="corrections per pass over P in the `deferred` leg (0 / 1: skip that leg)")
+    ap.add_argument("--deferred-steps", type=int, default=0,
+                    help="timed steps of the deferred legs (default: 40 batches; always whole batches)")
     ap.add_argument("--async-flush", action="store_true",
-                    help="run each pass over P on a second stream into a second tile store (measured: no gain, see "
-                         "profiles/round1_tuning.md sweep 6)")
+                    help="deferred legs: run each pass over P on a second stream into a second tile store")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-immediate", action="store_true")
+    ap.add_argument("--no-deferred", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with one rank per GPU "
-                     "(python -m torch.distributed.run --nproc-per-node %d ...)" % (args.gpus, args.gpus))
-        args.gpus = world
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
 
     import torch
     from ekf_slam_amd import Engine
@@ -147,6 +174,9 @@ def main():
     dist = None
     backend = os.environ.get("EKF_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the multi-rank flow on one GPU
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        sys.exit("bench.py: %d ranks but %d GPU(s) visible (one process per GPU; EKF_BENCH_BACKEND=gloo rehearses on one)"
+                 % (world, ndev))
     device = local_rank % max(ndev, 1)
     if world > 1:
         import torch.distributed as dist
@@ -161,9 +191,20 @@ def main():
     seed = 20260101 + 3
     w, x, s, d, U = make_state(N, seed)
     Rc = [.01, 5.0]                                           # EKF_SLAM.m:13
-    total = args.warmup + args.steps
+    batch = args.batch if args.batch > 1 and not args.no_deferred else 0
+    d_steps = 0
+    if batch:
+        d_steps = args.deferred_steps if args.deferred_steps > 0 else 40 * batch
+        d_steps = max(batch, (d_steps // batch) * batch)       # whole batches: every launch applies `batch` pairs
+    d_warm = 4 * batch
+    total = max(args.warmup + args.steps, d_warm + d_steps)
     steps = make_steps(w, N, total, Rc)
-    b_alg_rank = 8 * n * (n + 1) / world                      # every unique entry read + written once
+    b_alg = 8 * n * (n + 1)                                   # every unique entry read + written once
+    b_alg_rank = b_alg / world
+    # lower-order bytes of one update-step (9 n w for the 5 gathered rows, G and K), and what a deferred step
+    # adds: its (K, G) pair is written once by the gather and read once by the flush (2 x 32 n bytes)
+    b_small = 9 * n * 8
+    b_pair = 2 * 32 * n
 
     def barrier(e):
         e.sync()
@@ -171,7 +212,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    conditioned = [False]
+    conditioning = {"steps": 0}
 
     def run_leg(batch, nsteps, nwarm, lookahead=False):
         e = Engine(mode="known", capacity=N, tile=args.tile, device=device, rank=rank, world=world, batch=batch,
@@ -180,7 +221,8 @@ def main():
         transport = "none"
         if world > 1:
             from ekf_slam_amd.sharding import attach_communicator
-            transport = attach_communicator(e, dist, torch, prefer="rccl" if backend == "nccl" else "torch")
+            # nccl: the library's own RCCL communicator or an error (no silent second transport); gloo: the rehearsal path
+            transport = attach_communicator(e, dist, torch, transport="rccl" if backend == "nccl" else "torch")
 
         def run(chunk):
             # `chunk` is a marshalled run (Engine.marshal_steps): per step the host only passes addresses -- the per-call
@@ -199,24 +241,27 @@ def main():
                     e.step_raw(chunk, i)
             e.flush()
 
-        # Device conditioning, outside the contract's W warm-up steps: the first sustained burst of launches in a
-        # process sees a one-off 35-70 ms device stall (measured with scripts/probe_queue.py; it does not depend on
-        # the queue depth).  Burn it here, then restore the initial state so that W + K steps are the stated workload.
-        if not conditioned[0]:
-            run(e.marshal_steps((steps * (1 + 448 // max(len(steps), 1)))[:448]))
+        # Device conditioning, outside the contract's W warm-up steps and reported as `conditioning_steps`: the first
+        # sustained burst of launches in a process sees a one-off 35-70 ms device stall (scripts/probe_queue.py; it does
+        # not depend on the queue depth).  Burn it once, then restore the initial state so that W + K steps are the
+        # stated workload.
+        if not conditioning["steps"]:
+            ncond = 448 if batch > 1 else 64
+            run(e.marshal_steps((steps * (1 + ncond // max(len(steps), 1)))[:ncond]))
             barrier(e)
             e.load_lowrank_state(x, s, d, U)
-            conditioned[0] = True
+            conditioning["steps"] = ncond
         warm_run, timed_run = e.marshal_steps(steps[:nwarm]), e.marshal_steps(steps[nwarm:nwarm + nsteps])
         run(warm_run)
         barrier(e)
-        e.timing_enable(L.EKF_KERNEL_DOWNDATE, True)
+        e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=nsteps + 8)
         barrier(e)
         t0 = time.perf_counter()
         run(timed_run)
         barrier(e)
         dt = time.perf_counter() - t0
         launches, kernel_ms = e.timing_read(L.EKF_KERNEL_DOWNDATE)
+        kernel, kpairs = e.downdate_kernel_name()                # what the launcher actually chose for the last launch
         e.timing_enable(L.EKF_KERNEL_DOWNDATE, False)
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -232,39 +277,48 @@ def main():
         e.close()
         avg_ms = kernel_ms / max(launches, 1)
         achieved = b_alg_rank / (avg_ms * 1e-3)
+        per_launch = nsteps / max(launches, 1)
+        pmc = load_committed_pmc(N, args.tile, kpairs) if world == 1 else None
+        if pmc is not None and pmc.get("kernel") and pmc["kernel"] not in kernel:
+            pmc = None                                           # measured on another kernel: does not describe this launch
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK,
-                "traffic": load_traffic(N, args.tile, batch) if world == 1 else None,
-                "kernel": ("k_flush_mfma" if (batch > 1 and args.tile == 128) else "k_downdate_w" if args.tile >= 64 else "k_downdate"), "launches": launches,
+                # HBM bytes per launch from PMC counters: they need their own rocprofv3 passes (MI355X_MICROARCH.md), so the
+                # figure comes from the committed summary of exactly this launch shape -- null when none matches this run
+                "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                "from_committed_profile": pmc,
+                "kernel": kernel, "pairs_per_launch": kpairs, "launches": launches,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg_rank,
-                "update_steps_per_launch": nsteps / max(launches, 1),
-                # f64 matrix-pipe busy fraction of this kernel (PMC, committed summary); null where it was not measured
-                "matrix_pipe_busy": load_matrix_pipe(N, args.tile, batch) if world == 1 else None}
-        return {"value": nsteps / dt, "ms_per_step": dt / nsteps * 1e3, "roofline": roof, "transport": transport,
-                "state_finite": finite, "x_end": x_end, "digest": digest}
+                "update_steps_per_launch": per_launch}
+        # algorithmic bytes one update-step moves on this rank: the pass over (this rank's share of) P divided by the steps
+        # it serves, + the gathered rows / G / K (replicated on every rank), + the pending pair's write and read when deferred
+        b_step = b_alg_rank / max(per_launch, 1e-9) + b_small + (b_pair if batch > 1 else 0)
+        ms_step = dt / nsteps * 1e3
+        return {"value": nsteps / dt, "ms_per_step": ms_step, "steps": nsteps, "warmup": nwarm, "deferred_batch": batch,
+                "algorithmic_bytes_per_step": b_step, "effective_GBps": b_step / (ms_step * 1e-3) / 1e9,
+                "roofline": roof, "transport": transport, "state_finite": finite, "x_end": x_end, "digest": digest}
 
-    head = run_leg(args.batch, args.steps, args.warmup)
-    look = None
-    if world > 1 and args.batch > 1:
-        try:
-            look = run_leg(args.batch, args.steps, args.warmup, lookahead=True)
-        except Exception as ex:  # noqa: BLE001 -- an argument / state error is raised identically on every rank: report, go on
-            print("[rank %d] lookahead leg failed: %s" % (rank, ex), file=sys.stderr, flush=True)
-            look = None
-    imm = None
-    if not args.no_immediate and args.batch > 1:
-        n_imm = min(args.steps, 128)
-        imm = run_leg(1, n_imm, min(args.warmup, 16))
+    def public(leg, note):
+        out = {k: leg[k] for k in ("value", "ms_per_step", "steps", "warmup", "deferred_batch", "algorithmic_bytes_per_step",
+                                   "effective_GBps", "roofline", "state_finite")}
+        out["note"] = note
+        out["state_digest"] = [float(v) for v in leg["digest"]]
+        return out
 
-    # N > 1: the headline is the faster of the two exchange schedules (same arithmetic, same final state): one all-gather
-    # per update-step, or one per batch with the landmarks announced ahead (what ekf_measure does for a scan).
-    per_step = head
-    exchange = "none" if world == 1 else "all-gather per update-step"
-    if look is not None and look["state_finite"] and look["value"] > head["value"]:
-        head, exchange = look, "all-gather per batch (ekf_prefetch_rows)"
+    head = run_leg(1, args.steps, args.warmup)
+    dfr = look = None
+    if batch:
+        dfr = run_leg(batch, d_steps, d_warm)
+        if world > 1:
+            try:
+                look = run_leg(batch, d_steps, d_warm, lookahead=True)
+            except Exception as ex:  # noqa: BLE001 -- an argument / state error is raised identically on every rank: report, go on
+                print("[rank %d] lookahead leg failed: %s" % (rank, ex), file=sys.stderr, flush=True)
+                look = None
+
     if rank == 0:
         out = {
-            "metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I−KH)P vs roofline",
+            "metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I\u2212KH)P vs roofline",
             "value": head["value"],
             "unit": "update-steps/s",
             "n_gpus": world,
@@ -277,28 +331,31 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[2]: %d landmarks, known correspondence (EKF_SLAM.m), F64; step = 1 predict"
-                                   " + 1 correction on a cycling landmark; P split over %d GPU(s)" % (N, world),
+                                   " + 1 correction on a cycling landmark, P rewritten by every correction as written "
+                                   "(EKF_SLAM.m:145); P split over %d GPU(s)" % (N, world),
                        "landmarks": N, "state_dim": n, "tile": args.tile, "storage": "f64",
-                       "deferred_batch": args.batch, "async_flush": bool(args.batch > 1 and args.async_flush),
+                       "deferred_batch": 1,
                        "shard": "tile (I,J) on rank (I+J) mod %d" % world, "transport": head["transport"],
-                       "exchange": exchange,
+                       "exchange": "none" if world == 1 else "one all-gather of the 2 x 2N row-panel per update-step",
+                       "backend": backend if world > 1 else "none",
+                       "conditioning_steps": conditioning["steps"],
                        "state_finite": head["state_finite"],
                        # trace / sum / sum of squares of the final P (lower triangle): the same workload gives the same
-                       # digest on 1, 2, 4 or 8 GPUs and in deferred or immediate mode (to summation order)
+                       # digest on 1, 2, 4 or 8 GPUs (to summation order)
                        "state_digest": [float(v) for v in head["digest"]]},
+            "algorithmic_bytes_per_step": head["algorithmic_bytes_per_step"],
+            "effective_GBps": head["effective_GBps"],
             "roofline": head["roofline"],
         }
+        if dfr is not None:
+            out["deferred"] = public(dfr, "SURVEY.md 8f-1: the same workload with cfg.batch = %d -- corrections kept as pending rank-2 "
+                                          "pairs, ONE pass over P per %d update-steps (k_flush_mfma), bit-identical results; the "
+                                          "timed region ends with a flush.  Its own steps / warm-up / bytes per step are stated "
+                                          "here; `roofline` describes the flush launch%s"
+                                     % (batch, batch, "; one all-gather per update-step" if world > 1 else ""))
         if look is not None:
-            out["per_step_exchange"] = {"note": "same workload, one all-gather of the 2 x 2N row-panel per update-step",
-                                        "value": per_step["value"], "ms_per_step": per_step["ms_per_step"],
-                                        "roofline": per_step["roofline"]}
-            out["lookahead"] = {"note": "same workload; the host announces the landmarks of the next deferred_batch corrections "
-                                        "(ekf_prefetch_rows): one all-gather per batch instead of one per update-step",
-                                "value": look["value"], "ms_per_step": look["ms_per_step"], "roofline": look["roofline"],
-                                "state_digest": [float(v) for v in look["digest"]]}
-        if imm is not None:
-            out["immediate"] = {"deferred_batch": 1, "value": imm["value"], "ms_per_step": imm["ms_per_step"],
-                                "steps": min(args.steps, 128), "roofline": imm["roofline"]}
+            out["deferred_lookahead"] = public(look, "as `deferred`, with the landmarks of the next %d corrections announced "
+                                                     "(ekf_prefetch_rows): one all-gather per batch" % batch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, x, s, d, U, steps[args.warmup:])
         print(json.dumps(out), flush=True)

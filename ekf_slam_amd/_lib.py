@@ -74,6 +74,7 @@ SIGNATURES = {
     "ekf_get_P": (_i32, [_vp, _dp]),
     "ekf_set_P": (_i32, [_vp, _dp, _i64]),
     "ekf_get_P_block": (_i32, [_vp, _i64, _i64, _i64, _i64, _dp]),
+    "ekf_get_P_diag_blocks": (_i32, [_vp, _dp]),
     "ekf_get_Q": (_i32, [_vp, _dp]),
     "ekf_load_lowrank_state": (_i32, [_vp, _i64, _dp, _dp, _dp, _dp, _i64]),
     "ekf_checkpoint_save": (_i32, [_vp, ctypes.c_char_p]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "ekf_device_bytes": (_i32, [_vp, ctypes.POINTER(_i64)]),
     "ekf_kernel_timing_enable": (_i32, [_vp, _i32, _i32]),
     "ekf_kernel_timing_read": (_i32, [_vp, _i32, ctypes.POINTER(_i64), _dp]),
+    "ekf_downdate_kernel_name": (ctypes.c_char_p, [_vp, ctypes.POINTER(_i32)]),
     "ekf_downdate_algorithmic_bytes": (_i32, [_vp, ctypes.POINTER(_i64)]),
 }
 

@@ -124,6 +124,8 @@ struct ekf_handle {
     std::vector<void *> allocs;
     int64_t bytes = 0;
     int grid_cap = 0;
+    char dd_kernel[64] = "";       // kernel instance of the last downdate / flush launch (ekf_downdate_kernel_name)
+    int32_t dd_pairs = 0;          // pairs it applied
     std::string err;
 };
 
@@ -265,7 +267,8 @@ int32_t flush_pending(ekf_handle *h) {
     {
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
         HIPCHK(h, launch_downdate(h->st, h->st.tiles, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart, h->npend,
-                                  h->storage, h->grid_cap, h->stream));
+                                  h->storage, h->grid_cap, h->stream, h->dd_kernel));
+        h->dd_pairs = h->npend;
     }
     h->npend = 0;
     h->pstart = 0;
@@ -297,7 +300,8 @@ int32_t batch_complete(ekf_handle *h) {
             t->used += 2;
         }
         HIPCHK(h, launch_downdate(h->st, h->tilebuf[h->base ^ 1], h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart,
-                                  h->npend, h->storage, h->grid_cap, h->flush_stream));
+                                  h->npend, h->storage, h->grid_cap, h->flush_stream, h->dd_kernel));
+        h->dd_pairs = h->npend;
         if (stop) HIPCHK(h, hipEventRecord(stop, h->flush_stream));
     }
     HIPCHK(h, hipEventRecord(h->ev_flushed, h->flush_stream));
@@ -832,6 +836,13 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
         return fail(h, EKF_ERR_INVALID_ARG, "measure: bad argument");
     int32_t rc = use_device(h);
     if (rc) return rc;
+    // The loop below decides row by row whether to append or correct, and a correction on a shard needs an exchange in the
+    // middle of it: only the library-owned communicator can run that.  A host that runs the all-gather itself (transport (b)
+    // / (c) of ekfslam.h) drives append / correct_begin / its exchange / correct_finish per row -- refused here, up front,
+    // before any row has changed the state.
+    REQUIRE(h, !(h->sharded && h->comm == nullptr && m > 0), EKF_ERR_STATE,
+            "measure: a sharded handle needs the library-owned communicator (ekf_comm_init); with a host-run exchange call "
+            "ekf_append / ekf_correct_begin / ekf_correct_finish per observation");
     if (h->sharded && h->comm && h->batch > 1 && m > 1 && h->N > 0) {
         // the scan's corrections are known before the loop runs: fetch their base row-panels in ONE exchange
         // (rows that turn out to append drop the prefetch again; the per-row exchange then takes over)
@@ -1050,6 +1061,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
         HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
     }
     h->N = (n - 3) / 2;
+    h->pf_valid = false;       // a prefetch belongs to the state it was taken from
     h->s_host.resize((size_t)h->N, 0.0);
     HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1099,7 +1111,8 @@ int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
     int32_t rc = enter(h);
     if (rc) return rc;
     { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
-    h->npend = 0; h->pstart = 0;   // the whole covariance is replaced
+    h->npend = 0; h->pstart = 0;   // the whole covariance is replaced ...
+    h->pf_valid = false;           // ... and with it every prefetched base row-panel
     double *dense = nullptr;
     HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
     hipError_t e = hipMemcpyAsync(dense, P, (size_t)(n * n) * 8, hipMemcpyHostToDevice, h->stream);
@@ -1129,6 +1142,23 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
     return EKF_OK;
 }
 
+int32_t ekf_get_P_diag_blocks(ekf_handle *h, double *out) {
+    if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "get_P_diag_blocks: null argument");
+    int32_t rc = enter(h);
+    if (rc) return rc;
+    rc = flush_pending(h);
+    if (rc) return rc;
+    const size_t bytes = (size_t)(4 * (h->N + 1)) * 8;
+    double *d = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d, bytes));
+    hipError_t e = launch_get_diag_blocks(h->st, h->cur, h->N, d, h->storage, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(h, EKF_ERR_HIP, "get_P_diag_blocks", e);
+    return EKF_OK;
+}
+
 int32_t ekf_get_Q(ekf_handle *h, double Q[9]) {
     if (!h || !Q) return fail(h, EKF_ERR_INVALID_ARG, "get_Q: null argument");
     int32_t rc = enter(h);
@@ -1153,7 +1183,8 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     h->N = N;
     h->s_host.assign(s, s + N);
     { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
-    h->npend = 0; h->pstart = 0;   // the whole state is replaced
+    h->npend = 0; h->pstart = 0;   // the whole state is replaced ...
+    h->pf_valid = false;           // ... and with it every prefetched base row-panel
     rc = refresh_work(h);
     if (rc) return rc;
     double *dd = nullptr, *dU = nullptr;
@@ -1241,21 +1272,32 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     if (rc) return rc;
     FILE *f = fopen(path, "rb");
     REQUIRE(h, f != nullptr, EKF_ERR_STATE, "checkpoint_load: cannot open the file");
-    CkptHeader hd;
-    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM1", 8) != 0) { fclose(f); return fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM1 file"); }
-    if (hd.tile != h->T || hd.storage != h->storage || hd.world != h->cfg.world || hd.rank != h->cfg.rank || hd.N < 0 || hd.N > h->cap) {
-        fclose(f);
-        return fail(h, EKF_ERR_STATE, "checkpoint_load: tile edge, storage, shard or capacity do not match this handle");
-    }
-    const int64_t nmm = 2 * hd.N, nt = ekf_tiles_for(nmm, h->T);
-    if (hd.tile_bytes != h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h)) { fclose(f); return fail(h, EKF_ERR_STATE, "checkpoint_load: tile section size mismatch"); }
-    const size_t stage_bytes = (size_t)32 << 20;
     void *stage = nullptr;
-    if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { fclose(f); return fail(h, EKF_ERR_HIP, "checkpoint: staging buffer"); }
-    { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
+    // every exit below goes through here: the file is closed and the staging buffer released whatever happened
+    auto done = [&](int32_t status) { if (stage) hipHostFree(stage); fclose(f); return status; };
+    CkptHeader hd;
+    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM1", 8) != 0)
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM1 file"));
+    if (hd.tile != h->T || hd.storage != h->storage || hd.world != h->cfg.world || hd.rank != h->cfg.rank || hd.N < 0 || hd.N > h->cap)
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: tile edge, storage, shard or capacity do not match this handle"));
+    const int64_t nmm = 2 * hd.N, nt = ekf_tiles_for(nmm, h->T);
+    if (hd.tile_bytes != h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h))
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: tile section size mismatch"));
+    // the whole payload must be there BEFORE any device state is overwritten: a truncated file leaves the handle as it was
+    const int64_t payload = (3 + nmm) * 8 + hd.N * 8 + 9 * 8 + 3 * nmm * 8 + hd.tile_bytes;
+    if (fseek(f, 0, SEEK_END) != 0) return done(fail(h, EKF_ERR_STATE, "checkpoint_load: cannot seek"));
+    const long fsize = ftell(f);
+    if (fsize < 0 || (int64_t)fsize != (int64_t)sizeof hd + payload)
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: file length does not match its header (truncated?)"));
+    if (fseek(f, (long)sizeof hd, SEEK_SET) != 0) return done(fail(h, EKF_ERR_STATE, "checkpoint_load: cannot seek"));
+    const size_t stage_bytes = (size_t)32 << 20;
+    if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { stage = nullptr; return done(fail(h, EKF_ERR_HIP, "checkpoint: staging buffer")); }
+    rc = retire_inflight(h);
+    if (rc) return done(rc);
     h->npend = 0; h->pstart = 0; h->pf_valid = false; h->have_pp = false;
-    HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-    HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
+    hipError_t e = hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
+    if (e != hipSuccess) return done(fail(h, EKF_ERR_HIP, "checkpoint_load: clearing the pending pairs", e));
     std::vector<double> shost((size_t)hd.N);
     rc = stream_in(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
     if (!rc && hd.N > 0) {
@@ -1267,12 +1309,11 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     for (int r = 0; r < 3 && !rc && nmm > 0; ++r)
         rc = stream_in(h, f, h->st.strip[h->cur] + (size_t)r * h->st.ldm, (size_t)nmm * 8, stage, stage_bytes);
     if (!rc && hd.tile_bytes > 0) rc = stream_in(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
-    hipHostFree(stage);
-    fclose(f);
-    if (rc) return rc;
+    // N follows x even when a later section failed (an I/O error mid-way): x and N must never disagree
     h->N = hd.N;
     h->s_host = shost;
-    return EKF_OK;
+    h->work_rows = -1;
+    return done(rc);
 }
 
 int32_t ekf_P_digest(ekf_handle *h, double out[3]) {
@@ -1304,7 +1345,8 @@ int32_t ekf_kernel_timing_enable(ekf_handle *h, int32_t which, int32_t on) {
     KernelTimer &t = h->timers[which];
     if (on) {
         // create the event pool now: hipEventCreate inside a timed region costs tens of microseconds per launch
-        while (t.ev.size() < 2 * 512) {
+        const size_t reserve = on > 512 ? (size_t)on : 512;
+        while (t.ev.size() < 2 * reserve) {
             hipEvent_t e;
             HIPCHK(h, hipEventCreate(&e));
             t.ev.push_back(e);
@@ -1333,6 +1375,12 @@ int32_t ekf_kernel_timing_read(ekf_handle *h, int32_t which, int64_t *launches, 
     *total_ms = tot;
     t.used = 0;
     return EKF_OK;
+}
+
+const char *ekf_downdate_kernel_name(const ekf_handle *h, int32_t *pairs) {
+    if (!h) return "";
+    if (pairs) *pairs = h->dd_pairs;
+    return h->dd_kernel;
 }
 
 int32_t ekf_downdate_algorithmic_bytes(ekf_handle *h, int64_t *bytes) {

@@ -97,8 +97,9 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // used when several pairs are applied so that each XCD's K/G working set stays inside its own L2
 // dst: tile store the result is written to (== st.tiles for an in-place flush; a second buffer for the asynchronous
 // flush, which must not disturb kernels still reading st.tiles); pstart: ring slot of the first pair
+// kname: nullptr, or 64 bytes that receive the name of the kernel instance that was launched ("k_flush_mfma<double,128,8>")
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s);
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s);
@@ -107,6 +108,8 @@ hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double
 hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s);
 hipError_t launch_get_block(const DevState &st, int cur, int64_t r0, int64_t c0, int64_t nr, int64_t nc,
                             double *out, int storage, hipStream_t s);
+// out (device, 4 * (N+1) doubles): P(1:2,1:2), then the 2x2 diagonal block of every landmark, each column-major
+hipError_t launch_get_diag_blocks(const DevState &st, int cur, int64_t N, double *out, int storage, hipStream_t s);
 // P = diag(d) + U U' (d: n, U: n x k column-major, device)
 hipError_t launch_lowrank(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, const double *d,
                           const double *U, int64_t k, int storage, hipStream_t s);

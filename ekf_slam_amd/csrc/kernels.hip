@@ -15,6 +15,7 @@
 //   k_associate  per-landmark phi_k, Mahalanobis + signature     Correspondence.m:49-87
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "device_math.h"
@@ -1066,6 +1067,17 @@ __global__ __launch_bounds__(kBlock) void k_get_block(DevState st, int cur, int6
     out[e] = p_at<TS>(st, cur, r0 + r, c0 + c);
 }
 
+// what plot() reads (EKF_SLAM.m:180,205): P(1:2,1:2) and every landmark's 2x2 diagonal block, 4 doubles each, column-major
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_get_diag_blocks(DevState st, int cur, int64_t N, double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= 4 * (N + 1)) return;
+    const int64_t b = e >> 2;
+    const int r = (int)(e & 1), c = (int)((e >> 1) & 1);
+    const int64_t j = b == 0 ? 0 : 3 + 2 * (b - 1);
+    out[e] = p_at<TS>(st, cur, j + r, j + c);
+}
+
 // P = diag(d) + U U'.  Grid: x over (row, column-chunk) of the lower triangle in tile units is not needed
 // here (one-off bulk load): one thread per lower-triangle element of the padded tile grid.
 template <typename TS>
@@ -1454,10 +1466,17 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
     }
 }
 
+// what was launched, for the measurement hooks (ekf_downdate_kernel_name): "k_xxx<double,128,4,false>"
+static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, int xcd) {
+    if (!out) return;
+    if (xcd < 0) snprintf(out, 64, "%s<%s,%d,%d>", base, elt == 8 ? "double" : "float", T, p3);
+    else snprintf(out, 64, "%s<%s,%d,%d,%s>", base, elt == 8 ? "double" : "float", T, p3, xcd ? "true" : "false");
+}
+
 // the MFMA flush for the (storage type, tile edge) pairs it exists for; false: not applicable, use the VALU kernels
 template <typename TS, int T>
 static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_xcd, int64_t xcd_len, int pstart, int npairs,
-                              int grid_cap, hipStream_t s) {
+                              int grid_cap, hipStream_t s, char *kname) {
     constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
     if constexpr (kHave) {
         static const bool use_mfma = [] { const char *v = getenv("EKF_FLUSH_MFMA"); return !v || atoi(v) != 0; }();
@@ -1475,6 +1494,7 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         else
             hipLaunchKernelGGL((k_flush_mfma<TS, T, 8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
                                work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        name_kernel(kname, "k_flush_mfma", sizeof(TS), T, npairs <= chunk_switch ? 4 : 8, -1);
         return true;
     } else {
         return false;
@@ -1483,10 +1503,10 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
 
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
-                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s) {
+                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
-    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s)) return hipGetLastError();
+    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)) return hipGetLastError();
     if constexpr (kLanes == 64 || kLanes == 32) {
         static const bool use_lds = [] { const char *v = getenv("EKF_FLUSH_LDS"); return !v || atoi(v) != 0; }();
         if constexpr (sizeof(TS) == 8 && T == 128 && kSlab == 32) {
@@ -1495,6 +1515,7 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
                 if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
                 hipLaunchKernelGGL((k_flush_lds<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
                                    work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                if (kname) snprintf(kname, 64, "k_flush_lds<8>");
                 return hipGetLastError();
             }
         }
@@ -1503,17 +1524,20 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
             hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
                                (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+            name_kernel(kname, "k_downdate_w", sizeof(TS), T, kSlab, 1);
         } else {
             int64_t grid = nwork * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
             hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
                                (TS *)dstv, work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+            name_kernel(kname, "k_downdate_w", sizeof(TS), T, kSlab, 0);
         }
     } else {
         int64_t grid = nwork * (T / kSlab);
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         hipLaunchKernelGGL((k_downdate<TS, T, kSlab>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
                            work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        name_kernel(kname, "k_downdate", sizeof(TS), T, kSlab, -1);
     }
     return hipGetLastError();
 }
@@ -1527,10 +1551,10 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
 // K wave-uniform); T = 16 / 32 (generic kernel) and T = 64 exist for small maps and tests.
 template <typename TS>
 static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
-                                    int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s) {
+                                    int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s, char *kname) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -1556,12 +1580,12 @@ static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *
 }
 
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s) {
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname) {
     static const int slab1 = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
     static const int slabm = [] { const char *v = getenv("EKF_DOWNDATE_SLAB_BATCH"); return v ? atoi(v) : 0; }();
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s)
-                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s);
+    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname)
+                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
@@ -1600,6 +1624,14 @@ hipError_t launch_get_block(const DevState &st, int cur, int64_t r0, int64_t c0,
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL(k_get_block<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, r0, c0, nr, nc, out),
         hipLaunchKernelGGL(k_get_block<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, r0, c0, nr, nc, out));
+    return hipGetLastError();
+}
+
+hipError_t launch_get_diag_blocks(const DevState &st, int cur, int64_t N, double *out, int storage, hipStream_t s) {
+    const int64_t grid = cdiv(4 * (N + 1), kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_get_diag_blocks<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, N, out),
+        hipLaunchKernelGGL(k_get_diag_blocks<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, N, out));
     return hipGetLastError();
 }
 

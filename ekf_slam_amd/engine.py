@@ -236,6 +236,13 @@ class Engine:
         self._check(self.lib.ekf_get_P_block(self.h, r0, c0, nr, nc, _p(buf)))
         return buf.reshape(nr, nc, order="F")
 
+    def get_P_diag_blocks(self):
+        """(N+1) x 2 x 2: P(1:2,1:2) and every landmark's diagonal block -- what plot() reads, one call."""
+        nb = self.N + 1
+        buf = np.empty(4 * nb)
+        self._check(self.lib.ekf_get_P_diag_blocks(self.h, _p(buf)))
+        return buf.reshape(nb, 2, 2).transpose(0, 2, 1).copy()      # each block arrives column-major
+
     def get_Q3(self):
         q = np.empty(9)
         self._check(self.lib.ekf_get_Q(self.h, _p(q)))
@@ -273,8 +280,15 @@ class Engine:
         return int(b.value)
 
     # ---- measurement hooks ----
-    def timing_enable(self, which, on=True):
-        self._check(self.lib.ekf_kernel_timing_enable(self.h, which, 1 if on else 0))
+    def timing_enable(self, which, on=True, launches=0):
+        """launches: event pairs to reserve up front (launches expected between two timing_read calls)."""
+        self._check(self.lib.ekf_kernel_timing_enable(self.h, which, max(1, int(launches)) if on else 0))
+
+    def downdate_kernel_name(self):
+        """(name, pairs) of the kernel instance the last downdate / flush launch used, as the launcher chose it."""
+        pairs = ctypes.c_int32()
+        name = self.lib.ekf_downdate_kernel_name(self.h, ctypes.byref(pairs))
+        return (name or b"").decode(), int(pairs.value)
 
     def timing_read(self, which):
         n, ms = ctypes.c_int64(), ctypes.c_double()

@@ -5,8 +5,8 @@ robot block and the robot/landmark strip are replicated.  The only data-path exc
 update-step of the 2 x 2N landmark row-panel (chunk k of T columns comes from shard (tile_row(j)+k) mod world).
 
   * ``attach_communicator``  one process per GPU (torchrun): gives the handle a native RCCL communicator
-                             (ncclUniqueId from rank 0, broadcast through torch.distributed); if that fails it
-                             falls back to running the all-gather through torch.distributed itself.
+                             (ncclUniqueId from rank 0, broadcast through torch.distributed) -- or raises on every
+                             rank; a host-run all-gather through torch.distributed only on explicit request.
   * ``ShardGroup``           every shard of one filter driven from ONE host thread in one process (what a
                              MATLAB host does; also how the sharded path is tested on a single GPU).
   * ``owner`` / ``panel_source`` host-only views of the shard plan.
@@ -35,32 +35,48 @@ def panel_source(world, tile_row_j, chunk):
     return int(o.value), int(k.value)
 
 
-def attach_communicator(engine, dist, torch, prefer="rccl"):
-    """Give a sharded Engine its exchange.  Returns the transport actually in use."""
+def attach_communicator(engine, dist, torch, transport="rccl"):
+    """Give a sharded Engine its exchange.  Collective over all ranks.  Returns the transport in use.
+
+    transport="rccl": the library's own RCCL communicator (ekf_comm_init; ncclUniqueId from rank 0, broadcast through
+    torch.distributed).  If it cannot be attached on ANY rank this raises on EVERY rank -- there is no second transport
+    behind it.  Everything that can fail on one rank alone (loading librccl, creating the id) is agreed on with an
+    all_reduce BEFORE the collective ncclCommInitRank, so no rank is left waiting inside it.
+    transport="torch": the all-gather is run by the host through torch.distributed between ekf_correct_begin / _finish
+    (transport (b) of include/ekfslam.h): an explicit choice for rehearsals (gloo on one GPU), never a fallback."""
     world, rank = engine.cfg.world, engine.cfg.rank
-    if prefer == "rccl":
-        ok = torch.ones(1, dtype=torch.int32, device="cuda")
-        try:
-            buf = torch.zeros(L.EKF_COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
-                rc = L.lib().ekf_comm_unique_id(raw)
-                if rc:
-                    raise L.EkfError(rc, "ekf_comm_unique_id")
+    if transport not in ("rccl", "torch"):
+        raise ValueError("transport must be 'rccl' or 'torch'")
+    on_gpu = dist.get_backend() == "nccl"
+    dev = "cuda" if on_gpu else "cpu"
+    if transport == "rccl":
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        buf = torch.zeros(L.EKF_COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        why = ""
+        if rank == 0:
+            raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+            rc = L.lib().ekf_comm_unique_id(raw)
+            if rc:
+                ok.zero_()
+                why = "ekf_comm_unique_id failed (status %d): librccl not loadable?" % rc
+            else:
                 buf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
-            dist.broadcast(buf, src=0)
-            engine.comm_init(bytes(buf.cpu().numpy().tobytes()))
-        except Exception as ex:  # noqa: BLE001 -- any failure selects the torch transport on EVERY rank
-            print("[rank %d] native RCCL communicator unavailable (%s); using torch.distributed all_gather" % (rank, ex),
-                  flush=True)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                # agree BEFORE the collective init
+        if int(ok.item()) != 1:
+            raise L.EkfError(L.EKF_ERR_COMM, "native RCCL communicator unavailable on some rank" + (": " + why if why else ""))
+        dist.broadcast(buf, src=0)
+        err = ""
+        try:
+            engine.comm_init(bytes(buf.cpu().numpy().tobytes()))    # collective: ncclCommInitRank
+        except L.EkfError as ex:
             ok.zero_()
+            err = str(ex)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            return "rccl-native"
-        if engine.lib.ekf_last_error(engine.h):
-            pass
-    # host-run exchange over torch.distributed (RCCL underneath with backend "nccl"): the handle launches on
-    # torch's current stream so that the collective is ordered between extract and solve
+        if int(ok.item()) != 1:
+            raise L.EkfError(L.EKF_ERR_COMM, "ekf_comm_init failed on some rank" + (": " + err if err else ""))
+        return "rccl-native"
+    # host-run exchange over torch.distributed: the handle launches on a torch stream so that the collective is ordered
+    # between extract and solve
     _, _, _, cap = engine.exchange_info()
     send = torch.zeros(cap, dtype=torch.float64, device="cuda")
     recv = torch.zeros(cap * world, dtype=torch.float64, device="cuda")
@@ -70,7 +86,7 @@ def attach_communicator(engine, dist, torch, prefer="rccl"):
     xstream = torch.cuda.Stream()
     engine.set_stream(xstream.cuda_stream)
     engine._xchg_tensors = (send, recv, xstream)
-    staged = dist.get_backend() != "nccl"      # e.g. gloo (rehearsals on one GPU): stage through host memory
+    staged = not on_gpu                        # e.g. gloo (rehearsals on one GPU): stage through host memory
 
     def host_exchange(e):
         _, _, cnt, _ = e.exchange_info()

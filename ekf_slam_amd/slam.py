@@ -45,13 +45,28 @@ class _EkfBase:
     def x(self):
         return self._e.get_x()
 
+    @x.setter
+    def x(self, v):                 # assignable like the reference's (EKF_SLAM.m:6-9); x fixes the landmark count
+        v = _vec(v)
+        self._e._check(self._e.lib.ekf_set_x(self._e.h, _p(v), v.size))
+
     @property
     def P(self):
         return self._e.get_P()
 
+    @P.setter
+    def P(self, v):
+        Pf = np.asfortranarray(np.asarray(v, dtype=np.float64))
+        self._e._check(self._e.lib.ekf_set_P(self._e.h, _p(Pf.reshape(-1, order="F")), Pf.shape[0]))
+
     @property
     def s(self):
         return self._e.get_s()
+
+    @s.setter
+    def s(self, v):
+        v = _vec(v)
+        self._e._check(self._e.lib.ekf_set_s(self._e.h, _p(v) if v.size else None, v.size))
 
     @property
     def Q(self):
@@ -115,11 +130,17 @@ class _EkfBase:
 
     def plot_data(self):
         """What plot() reads: pose and the 2x2 diagonal blocks of P (EKF_SLAM.m:180,205)."""
-        x = self.x
-        blocks = [self._e.get_P_block(0, 0, 2, 2)]
-        for k in range(self._e.N):
-            blocks.append(self._e.get_P_block(3 + 2 * k, 3 + 2 * k, 2, 2))
-        return x, blocks
+        return self.x, list(self._e.get_P_diag_blocks())
+
+    def plot(self, landmark_list=None):
+        """plot(h, landmark_list) (EKF_SLAM.m:154-234) minus the drawing: returns what the figure is made of -- pose,
+        landmark positions, the 2x2 covariance blocks -- and forwards to the landmark source's own plot if it has one
+        (EKF_SLAM.m:167)."""
+        x, blocks = self.plot_data()
+        src = getattr(landmark_list, "landmarkObj", None)
+        if src is not None and hasattr(src, "plot"):
+            src.plot(x, self.observed)
+        return {"pose": x[:3], "landmarks": x[3:].reshape(-1, 2), "covariance_blocks": blocks}
 
     def sync(self):
         self._e.sync()
@@ -225,6 +246,10 @@ class SLAM:
     def measure(self, laserdata, u):
         if self.slam is not None:
             self.slam.measure(laserdata, u, self.LM)
+
+    def plot(self):                               # SLAM.m:61-68
+        if self.slam is not None:
+            return self.slam.plot(self.LM)
 
     def runSlam(self):
         """One SLAM iteration: predict then measure (SLAM.m:105-116)."""

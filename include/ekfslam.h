@@ -179,6 +179,9 @@ int32_t ekf_get_P(ekf_handle *h, double *P);
 int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n);
 /* P(r0:r0+nr-1, c0:c0+nc-1) into out (nr x nc column-major): what plot() reads (EKF_SLAM.m:180,205). */
 int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64_t nc, double *out);
+/* Everything plot() reads of P in ONE call (EKF_SLAM.m:180 robotSigma, :205 landmarkSigma): out holds 4 * (N+1) doubles --
+ * P(1:2,1:2), then the 2x2 diagonal block of landmark 1..N, each column-major.  NaN for blocks held by another shard. */
+int32_t ekf_get_P_diag_blocks(ekf_handle *h, double *out /* 4*(N+1) */);
 /* The 3x3 non-zero block of the last predict's Q (EKF_SLAM.m:43-44), column-major. */
 int32_t ekf_get_Q(ekf_handle *h, double Q[9]);
 /* Bulk state load used to start large benchmarks: sets N landmarks, x (3+2N), s (N) and
@@ -202,10 +205,15 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path);
 /* ---- measurement hooks ---- */
 enum { EKF_KERNEL_DOWNDATE = 0, EKF_KERNEL_GATHER = 1, EKF_KERNEL_PREDICT = 2, EKF_KERNEL_ASSOCIATE = 3,
        EKF_KERNEL_APPEND = 4, EKF_KERNEL_COUNT = 5 };
-/* Bracket every launch of kernel `which` with HIP events on the handle's stream (on != 0) and read the
+/* Bracket every launch of kernel `which` with HIP events on the handle's stream (on != 0; on > 512 also reserves
+ * event pairs for that many launches between two reads, so that none is created inside a timed region) and read the
  * accumulated launch count and device time; reading synchronises the stream and resets the counters. */
 int32_t ekf_kernel_timing_enable(ekf_handle *h, int32_t which, int32_t on);
 int32_t ekf_kernel_timing_read(ekf_handle *h, int32_t which, int64_t *launches, double *total_ms);
+/* Name of the kernel instance the LAST downdate / flush launch of this handle used, as the launcher chose it
+ * (e.g. "k_downdate_w<double,128,4,false>", "k_flush_mfma<double,128,8>"), and the number of pending pairs it applied
+ * (*pairs, may be NULL); "" before the first launch.  The string is owned by the handle. */
+const char *ekf_downdate_kernel_name(const ekf_handle *h, int32_t *pairs);
 /* Algorithmic bytes one launch of the downdate kernel moves at the current N: every unique entry of the
  * symmetric P read once and written once = w * n * (n+1), n = 3+2N. */
 int32_t ekf_downdate_algorithmic_bytes(ekf_handle *h, int64_t *bytes);

@@ -109,7 +109,7 @@ else:
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from ekf_slam_amd.sharding import attach_communicator
-    transport = attach_communicator(e, dist, torch, prefer=mode)
+    transport = attach_communicator(e, dist, torch, transport=mode)
 for idx0 in (0, 50, 119, 7):
     z = [rng.uniform(1, 30), rng.uniform(1, 359)]; R = np.diag([z[0] * .01, z[1] * 5.0])
     e.predict([0.1, 3.0]); ref.predict([0.1, 3.0])
