@@ -1,6 +1,7 @@
 """CPU tests of the oracle (test infrastructure): hand-derived known-answer tests from the reference source
-(SURVEY.md section 4, KAT-1..4 -- the reference itself holds no golden vectors: PARITY UNPINNED), and
-literal-dense == structured agreement."""
+(SURVEY.md section 4, KAT-1..4, and KAT-5..7 for the correction body, append and association -- derivations in
+tests/kat_cases.py; the reference itself holds no golden vectors: PARITY UNPINNED), and literal-dense == structured
+agreement.  The GPU twins of KAT-5..7 are in tests/test_kat_gpu.py."""
 import numpy as np
 import pytest
 
@@ -8,6 +9,8 @@ from ekf_slam_amd.world import SyntheticLandmark, make_run
 from oracle import ekf_dense as D
 from oracle.ekf_structured import StructuredEKF
 from oracle.matlab_compat import atan2d, cosd, inv2, sind, wrapTo360
+
+import kat_cases as K
 
 
 def rel_err(a, b):
@@ -95,6 +98,58 @@ def test_append_free_function_guard():
     x3, P3 = D.append(x, P, [0.1, 1], 2, np.eye(2), [2, 2])
     assert len(x3) == 7 and P3.shape == (7, 7)
     np.testing.assert_allclose(P3, P3.T, atol=1e-15)
+
+
+def test_kat5_correction_body_by_hand(oracle_lib):
+    """EKF_SLAM.m:124-145 on the paper case of tests/kat_cases.py (KAT-5): exact rationals, both restatements."""
+    d = D.EKF_SLAM()
+    d.x, d.P, d.s = K.K5_X.copy(), K.K5_P.copy(), [1]
+    d._correct(K.K5_Z, K.K5_R, 1)
+    st = StructuredEKF(4, "known")
+    st.set_state(K.K5_X, K.K5_P, [1.0])
+    st.correct(K.K5_Z, K.K5_R, 1)
+    for x, P in ((d.x, d.P), (st.x, st.P)):
+        np.testing.assert_allclose(x, K.K5_X_OUT, rtol=0, atol=2e-16)
+        np.testing.assert_allclose(P, K.K5_P_OUT, rtol=0, atol=2e-16)
+
+
+def test_kat6_append_twice_by_hand(oracle_lib):
+    """EKF_SLAM.m:67-98 (KAT-6): two appends from the KAT-1 state, incl. the old-landmark loop :94-97."""
+    d = D.EKF_SLAM()
+    st = StructuredEKF(4, "known")
+    for e in (d, st):
+        e.predict([1, 0])
+        for a in K.K6_APPENDS:
+            e.append(a["u"], a["R"], a["pos"], a["sig"])
+        np.testing.assert_allclose(e.x, K.K6_X_OUT, rtol=0, atol=0)
+        np.testing.assert_allclose(e.P, K.K6_P_OUT, rtol=0, atol=4e-15)        # 17 = 1.0 + 16 carries one rounding of .1 sums
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), K.K6_S_OUT)
+    # free function append.m:1-27 gives the same first append and refuses the guarded one
+    x1, P1 = D.append([1.0, 0, 0], np.array([[.3, 0, 0], [0, .2, .1], [0, .1, .1]]), K.K6_APPENDS[0]["u"], 1,
+                      K.K6_APPENDS[0]["R"], K.K6_APPENDS[0]["pos"])
+    np.testing.assert_allclose(P1, K.K6_P_OUT[:5, :5], rtol=0, atol=4e-15)
+    x2, _ = D.append(x1, P1, [2, 180], 1, np.eye(2), [9, 9])                    # numOfLandmarks (1) < idx (1) is false
+    assert len(x2) == 5
+
+
+def test_kat7_association_costs_by_hand(oracle_lib):
+    """Correspondence.m:49-87 (KAT-7): Mahalanobis cost per landmark, live (signature-only) and commented-out (position +
+    signature) likelihoods, threshold and tie rules."""
+    c = D.Correspondence(1.0, 1e9, 'EKF_SLAM_UC')
+    for z, pc in ((K.K7_ZA, K.K7_PC_A), (K.K7_ZB, K.K7_PC_B)):
+        assert c.estimateCorrespondence(z, K.K7_R, K.K7_X, K.K7_P, K.K7_S) == (False, 1)      # :75 live line: tie -> first
+        np.testing.assert_allclose(c.last_position_cost, pc, rtol=1e-14)
+        np.testing.assert_array_equal(c.last_signature_cost, [0.0, 0.0])
+    for w_pos, thresh, z, want in [(0.0, 1e9, K.K7_ZA, (False, 1)), (0.0, 1e9, K.K7_ZB, (False, 1)),
+                                   (1.0, 1e9, K.K7_ZA, (False, 1)), (1.0, 1e9, K.K7_ZB, (False, 2)),
+                                   (1.0, 100.0, K.K7_ZA, (False, 1)), (1.0, 2.0, K.K7_ZA, (True, 3)),
+                                   (1.0, 1e9, [4.2, 85.0, 6.0], (False, 2))]:
+        st = StructuredEKF(4, "uc", s_cost=1.0, s_thresh=thresh, w_pos=w_pos)
+        st.set_state(K.K7_X, K.K7_P, K.K7_S)
+        new, idx, pc, sc = st.associate(z, K.K7_R, want_costs=True)
+        assert (new, idx) == want, (w_pos, thresh, z)
+        np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
+        np.testing.assert_array_equal(sc, [(z[2] - 5.0) ** 2] * 2)
 
 
 @pytest.mark.parametrize("mode", ["known", "uc"])
