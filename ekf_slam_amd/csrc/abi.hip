@@ -597,6 +597,7 @@ int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
     cfg->world = 1;
     cfg->batch = 1;
     cfg->async_flush = 0;
+    cfg->device_assoc = 0;
     return EKF_OK;
 }
 
@@ -882,7 +883,7 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
             int32_t is_new = 0;
             int64_t idx = 0;
             static const bool force_dev = [] { const char *v = getenv("EKF_FORCE_DEVICE_ASSOC"); return v && atoi(v) != 0; }();
-            if (h->cfg.w_pos == 0.0 && !force_dev) {
+            if (h->cfg.w_pos == 0.0 && !force_dev && !h->cfg.device_assoc) {
                 // The reference's decision is a pure function of z(3) and s: the Mahalanobis position cost it also
                 // evaluates is discarded (Correspondence.m:74-75).  With w_pos == 0 measure() therefore decides from
                 // the host mirror of s -- same arithmetic as k_associate, no launch, no device->host sync.

@@ -73,7 +73,13 @@ typedef struct ekf_config {
                                     reading the current store plus all pending pairs; stores swap at the next
                                     batch boundary.  Same bits as async_flush = 0.  The second stream is confined
                                     to a CU mask that leaves 32 CUs (EKF_ASYNC_RESERVE_CUS) to the corrections. */
-    int32_t reserved[6];
+    int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure: 1 = every observation runs the association kernels on the device
+                                    (per-landmark phi_k, Mahalanobis and signature cost, arg-min: Correspondence.m:49-87 as
+                                    the reference evaluates it).  0 (default) = when w_pos == 0 the decision is taken from
+                                    the host mirror of s -- the reference's live likelihood is signature-only
+                                    (Correspondence.m:75), so the result is the same, without a launch and a device->host
+                                    sync per observation.  ekf_associate() always runs on the device. */
+    int32_t reserved[5];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;

@@ -1,0 +1,50 @@
+"""GPU: BASELINE.json configs[1] at its stated size -- 1 000 landmarks, unknown correspondence (EKF_SLAM_UC.m +
+Correspondence.m), F64, one GPU -- against the structured oracle on the same inputs (seed 20260102,
+a warm-up sweep appends all 1 000 landmarks through measure(), then SLAM iterations of 1 predict + measure() over the 8
+nearest landmarks).  Run twice: with the association decided per observation by the device kernels (k_associate: per-landmark
+phi_k, Mahalanobis and signature cost, arg-min -- what the reference evaluates, Correspondence.m:49-87) and with the
+host-mirror shortcut that is legitimate because the reference's live likelihood is signature-only (Correspondence.m:75); both
+must give the same state bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+N, M, ITERS = 1000, 8, 40
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle.ekf_structured import StructuredEKF
+    _, run = make_run(N, 20260102, 2 + ITERS, policy="nearest", m=M)
+    gpus = {"device": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=True), "host": EKF_SLAM_UC(capacity=N, batch=8)}
+    lms = {k: Landmark('SYNTHETIC') for k in gpus}
+    ref, lr = StructuredEKF(N, "uc"), SyntheticLandmark()
+    for t, (u, scan) in enumerate(run):
+        for k, e in gpus.items():
+            e.predict(u); e.measure(scan, u, lms[k])
+        ref.predict(u); ref.measure(scan, u, lr)
+        if t == 1:
+            assert ref.N == N and all(e._e.N == N for e in gpus.values())       # the sweep appended every landmark
+    # every later observation associated with an existing landmark: the map did not grow
+    assert ref.N == N and all(e._e.N == N for e in gpus.values())
+    xd, Pd = gpus["device"].x, gpus["device"].P
+    ex, eP = rel_err(xd, ref.x), rel_err(Pd, ref.P)
+    print("1k UC: %d iterations x %d observations, rel err x %.2e P %.2e" % (ITERS, M, ex, eP))
+    assert ex < REL and eP < REL
+    np.testing.assert_array_equal(gpus["host"].x, xd)
+    np.testing.assert_array_equal(gpus["host"].P, Pd)
+    np.testing.assert_array_equal(gpus["device"].s, ref.s)
+    # the device association agrees with the oracle's, costs included, on the final state (pending-free and with pending pairs)
+    z = np.asarray(gpus["device"].observed[0], dtype=np.float64)
+    R = np.diag([z[0] * .1, z[1] * 5.0])
+    new_g, idx_g, pc_g, sc_g = gpus["device"]._e.associate(z, R, want_costs=True)
+    new_r, idx_r, pc_r, sc_r = ref.associate(z, R, want_costs=True)
+    assert (new_g, idx_g + 1) == (new_r, idx_r)
+    assert rel_err(pc_g, pc_r) < REL and rel_err(sc_g, sc_r) < REL

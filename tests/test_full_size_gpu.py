@@ -1,4 +1,5 @@
-"""GPU: BASELINE.json's full size (10 000 landmarks, F64).  The structured oracle runs the same predict / correct
+"""GPU: BASELINE.json's full sizes (configs[2]: 10 000 landmarks, F64, one GPU; configs[3]: the same filter split over 8
+shards).  The structured oracle runs the same predict / correct
 steps on a full 20 003 x 20 003 matrix (3.2 GB); parity is checked on x (all of it), on the digests of P
 (trace / sum / sum of squares over the lower triangle), on the robot rows and on sampled blocks spread over first,
 middle and last tile rows, plus size-independent properties: trace non-increasing across a correction, and the
@@ -75,3 +76,78 @@ def test_ten_thousand_landmarks_against_oracle(oracle_lib):
         assert rel_err(a, Pv[r0:r0 + 6, c0:c0 + 6]) < REL
         np.testing.assert_array_equal(dfr.get_P_block(r0, c0, 6, 6), a)
     imm.close(); dfr.close()
+
+
+def _oracle_at(x, s, d, U):
+    from oracle.ekf_structured import StructuredEKF
+    n = 3 + 2 * N
+    ref = StructuredEKF(N, "known")
+    P = ref.raw_P()
+    for r0 in range(0, n, 2048):
+        r1 = min(n, r0 + 2048)
+        P[r0:r1, :n] = U[r0:r1] @ U.T
+    P[np.arange(n), np.arange(n)] += d
+    ref._x[:n] = x; ref._s[:N] = s
+    ref.L.oekf_set_num_landmarks(ref.h, N)
+    return ref
+
+
+def test_ten_thousand_landmarks_eight_shards(oracle_lib):
+    """BASELINE.json configs[3] at full size: the 10 000-landmark filter split over 8 shards (all on the one test GPU, one
+    process, ekf_exchange_local), deferred batch 32 with prefetched row-panels plus per-step exchanges -- against the
+    unsharded engine (x bit for bit, P digest to summation order, sampled blocks bit for bit) and against the structured
+    oracle on the same steps (x, digests, robot rows, sampled blocks: 1e-6)."""
+    import bench
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    world, batch = 8, 32
+    w, x, s, d, U = bench.make_state(N, 20260105)
+    n = 3 + 2 * N
+    ref = _oracle_at(x, s, d, U)
+    one = Engine(capacity=N, tile=128, batch=batch)
+    one.load_lowrank_state(x, s, d, U)
+    g = ShardGroup(world, capacity=N, tile=128, batch=batch)
+    g.load_lowrank_state(x, s, d, U)
+    R = np.diag([0.2, 50.0])
+    u = [0.1, 3.0]
+    k = 0
+    for rep in range(2):                                   # two full batches through ONE exchange each
+        idx = [((k + i) * 37) % N for i in range(batch)]
+        g.prefetch_rows(sorted(set(idx)))
+        for i in idx:
+            z = [10.0 + (i % 7), 100.0 + (i % 11)]
+            one.predict(u); one.correct(z, R, i)
+            g.predict(u); g.correct_local(z, R, i)
+            ref.predict(u); ref.correct(z, R, i + 1)
+        k += batch
+    assert g.shards[0].pending() == one.pending() == 0     # the batch boundary flushed every shard
+    for i in (5, 4242, 9999):                              # per-step exchange, pending pairs patched in k_rowpanel
+        z = [12.0, 77.0]
+        one.predict(u); one.correct(z, R, i)
+        g.predict(u); g.correct(z, R, i)
+        ref.predict(u); ref.correct(z, R, i + 1)
+    xs = g.get_x()                                         # asserts the replicated x is identical on all 8 shards
+    np.testing.assert_array_equal(xs, one.get_x())
+    assert rel_err(xs, ref._x[:n]) < REL
+    dg = sum(np.asarray(e.digest()) for e in g.shards)     # flushes the 3 pending pairs on every shard
+    d1 = one.digest()
+    np.testing.assert_allclose(dg, d1, rtol=1e-12)
+    Pv = ref._P
+    tr = float(np.trace(Pv[:n, :n]))
+    assert abs(dg[0] - tr) / abs(tr) < 1e-9
+    # every shard holds the replicated robot rows; landmark-block entries come from the owning shard (NaN elsewhere)
+    for e in (g.shards[0], g.shards[7]):
+        assert rel_err(e.get_P_block(0, 0, 3, n), Pv[0:3, :n]) < REL
+    rng = np.random.default_rng(2)
+    corners = [(3, 3), (3 + 2 * 63, 3), (3 + 2 * 5000, 3 + 2 * 4999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * 7777, 3 + 2 * 123)] + \
+              [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(20)]
+    for r0, c0 in corners:
+        a = one.get_P_block(r0, c0, 6, 6)
+        assert rel_err(a, Pv[r0:r0 + 6, c0:c0 + 6]) < REL
+        merged = np.full((6, 6), np.nan)
+        for e in g.shards:
+            b = e.get_P_block(r0, c0, 6, 6)
+            hole = np.isnan(merged)
+            merged[hole] = b[hole]
+        np.testing.assert_array_equal(merged, a)
+    g.close(); one.close()

@@ -62,32 +62,27 @@ def test_class_surface_matches_reference_names():
 
 
 def test_runslam_end_to_end_with_ransac_bookkeeping():
-    """SLAM('EKF_SLAM') with Landmark('RANSAC'): the reference's landmark-list bookkeeping (consensus counts, index
-    assignment, single observed row) fed with synthetic wall foot-points, against the literal-dense oracle driven by
-    its own copy of the same bookkeeping."""
+    """SLAM('EKF_SLAM') with Landmark('RANSAC') on the GPU -- the product's landmark-list bookkeeping fed with wall
+    foot-points -- against the literal-dense oracle driven by a HAND-SCRIPTED trace of what that bookkeeping must output
+    (tests/ransac_script.py: derived from RANSAC.m:234-334 on paper, no product class on the oracle side).  Checked at every
+    step: the observed row and the landmark table of the product equal the script's; at the end: x and P."""
+    import ransac_script as S
     from ekf_slam_amd import slam
-    from ekf_slam_amd.ransac_bookkeeping import RansacBookkeeping
     from oracle import ekf_dense as D
 
-    rng = np.random.default_rng(8)
-    walls = np.array([[2.0, 1.0], [-1.5, 2.5]])
-    feed = []
-    for t in range(45):
-        u = [0.05 + 0.001 * t, 2.0]
-        pts = walls[:1 if t < 20 else 2] + rng.normal(0, 0.01, (1 if t < 20 else 2, 2))
-        feed.append((u, pts))
+    feed = S.feed()
     s = slam.SLAM('EKF_SLAM', feed=feed, capacity=8, tile=16, landmark_method='RANSAC')
-
-    class _LM:                       # Landmark.m shape around the oracle's own bookkeeping object
-        def __init__(self):
-            self.landmarkObj = RansacBookkeeping()
-
-        def getLandmark(self, laser, x):
-            return self.landmarkObj.getLandmark(laser, x)
-    ref, lm = D.EKF_SLAM(), _LM()
-    for u, pts in feed:
+    ref, src = D.EKF_SLAM(), S.ScriptedSource()
+    for t, (u, pts) in enumerate(feed):
         s.runSlam()
-        ref.predict(u); ref.measure(pts, u, lm)
-    assert s.slam._e.N == (len(ref.x) - 3) // 2 >= 1
+        ref.predict(u); ref.measure(pts, u, src)
+        got = s.slam.observed
+        want = src.rows[-1]
+        assert got.shape == want.shape, t
+        if len(want):
+            assert got[0, 2] == want[0, 2] == S.expected_row_index(t)
+            np.testing.assert_allclose(got[0, :2], want[0, :2], rtol=1e-9)
+        assert [(e.index, tuple(e.loc)) for e in s.LM.landmarkObj.landmark] == \
+               [(i, tuple(loc)) for i, loc in S.expected_table(t)], t
+    assert s.slam._e.N == (len(ref.x) - 3) // 2 == 2
     assert rel_err(s.slam.x, ref.x) < REL and rel_err(s.slam.P, ref.P) < REL
-    assert [e.index for e in s.LM.landmarkObj.landmark] == [e.index for e in lm.landmarkObj.landmark]

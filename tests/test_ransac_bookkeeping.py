@@ -77,3 +77,22 @@ def test_table_shape_matches_what_measure_takes():
         r.getLandmark([[1.0, 0.0]], POSE)
     idx, loc = r.table()
     assert idx.tolist() == [1.0] and loc.shape == (1, 2)
+
+
+def test_bookkeeping_plays_the_hand_scripted_scenario():
+    """The scenario of tests/ransac_script.py (expected rows / tables derived on paper from RANSAC.m:234-334), with the poses
+    of the literal-dense oracle: the product's bookkeeping must reproduce it step by step."""
+    import ransac_script as S
+    from oracle import ekf_dense as D
+    ref, src, rb = D.EKF_SLAM(), S.ScriptedSource(), RansacBookkeeping()
+    for t, (u, pts) in enumerate(S.feed()):
+        ref.predict(u)
+        got = rb.getLandmark(pts, ref.x)
+        ref.measure(pts, u, src)                       # the oracle advances on the SCRIPTED source, not on `rb`
+        want = src.rows[-1]
+        assert got.shape == want.shape, t
+        if len(want):
+            assert got[0, 2] == S.expected_row_index(t)
+            np.testing.assert_allclose(got, want, rtol=1e-12)
+        assert [(e.index, tuple(e.loc)) for e in rb.landmark] == [(i, tuple(loc)) for i, loc in S.expected_table(t)], t
+    assert (len(ref.x) - 3) // 2 == 2

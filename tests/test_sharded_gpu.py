@@ -196,3 +196,56 @@ def test_prefetched_row_panels_need_no_per_step_exchange(world, batch, tile):
     g.correct([6.0, 60.0], R, N); one.correct([6.0, 60.0], R, N)
     np.testing.assert_array_equal(g.get_P(), one.get_P())
     g.close(); one.close()
+
+
+def test_state_load_drops_a_prefetch():
+    """A prefetch holds BASE row-panels of the covariance it was taken from: loading another state (ekf_set_P,
+    ekf_set_x, ekf_load_lowrank_state, a checkpoint) must drop it, or the next correction on a prefetched landmark would
+    silently solve against the old rows.  After the load a local correction has nothing to work from (EKF_ERR_STATE); the
+    exchanged correction matches the unsharded engine on the NEW state bit for bit."""
+    from ekf_slam_amd import Engine, EkfError, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 100
+    x, P, s, d, U = _state(N, 41)
+    x2, P2, s2, d2, U2 = _state(N, 42)
+    z, R = [7.0, 80.0], np.diag([0.07, 400.0])
+    for how in ("set_state", "set_P_only", "lowrank"):
+        g = ShardGroup(2, capacity=N, tile=16, batch=4)
+        one = Engine(capacity=N, tile=16, batch=4)
+        g.set_state(x, P, s); one.set_state(x, P, s)
+        g.prefetch_rows([5, 6])
+        if how == "set_state":
+            g.set_state(x2, P2, s2); one.set_state(x2, P2, s2)
+        elif how == "set_P_only":
+            for e in g.shards + [one]:
+                Pf = np.asfortranarray(P2)
+                e._check(e.lib.ekf_set_P(e.h, Pf.reshape(-1, order="F").ctypes.data_as(L._dp), Pf.shape[0]))
+        else:
+            g.load_lowrank_state(x2, s2, d2, U2); one.load_lowrank_state(x2, s2, d2, U2)
+        with pytest.raises(EkfError) as ei:
+            g.correct_local(z, R, 5)
+        assert ei.value.status == L.EKF_ERR_STATE, how
+        g.correct(z, R, 5); one.correct(z, R, 5)
+        np.testing.assert_array_equal(g.get_x(), one.get_x())
+        np.testing.assert_array_equal(g.get_P(), one.get_P())
+        g.close(); one.close()
+
+
+def test_measure_is_refused_up_front_on_a_shard_without_communicator():
+    """ekf_measure decides append / correct row by row and a correction on a shard needs an exchange: without the
+    library-owned communicator it is refused BEFORE any row changes the state (hosts that run the exchange themselves
+    drive append / correct_begin / finish per row)."""
+    from ekf_slam_amd import EkfError, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 20
+    x, P, s, _, _ = _state(N, 43)
+    g = ShardGroup(2, capacity=N + 2, tile=16)
+    g.set_state(x, P, s)
+    x0 = g.get_x()
+    obs = np.array([[5.0, 40.0, 1.0], [8.0, 70.0, N + 1.0]])
+    with pytest.raises(EkfError) as ei:
+        g.shards[0].measure(obs, [0.1, 3.0], np.arange(1, N + 2.0), np.zeros((N + 1, 2)))
+    assert ei.value.status == L.EKF_ERR_STATE and "communicator" in str(ei.value)
+    assert g.shards[0].N == N
+    np.testing.assert_array_equal(g.shards[0].get_x(), x0)
+    g.close()
