@@ -32,7 +32,7 @@ def test_f32_tiles_sharded_streaming_append(world, batch, oracle_lib):
     from ekf_slam_amd.sharding import ShardGroup
     from oracle.ekf_structured import StructuredEKF
     T = 256
-    N = 637                                   # 1274 landmark-block rows: 5 tile rows; the appends below cross into the 6th at 1280
+    N = 638                                   # 1276 landmark-block rows: 5 tile rows; the appends below cross into the 6th at 1280
     cap = N + 8
     x, P, s = _state(N, 71)
     g = ShardGroup(world, capacity=cap, tile=T, storage="f32", batch=batch)
@@ -60,13 +60,13 @@ def test_f32_tiles_sharded_streaming_append(world, batch, oracle_lib):
     for k, idx0 in enumerate([0, 127, 128, N - 1, 300, 5]):
         u, R = step(idx0, True)
         if k % 2 == 1:
-            grow(u, R)                        # N -> 638, 639 (rows 1276..1279: last slots of tile row 4), 640 (row 1280: tile row 5)
+            grow(u, R)                        # N -> 639, 640 (rows 1276..1279: last slots of tile row 4), 641 (rows 1280-1: tile row 5)
             step(g.N - 1, True)               # correct the landmark just appended
     assert g.N == one.N == ref.N == N + 3 and 2 * g.N > 5 * T
     if batch > 1:
         # one exchange for a batch (k_rowpanel_base<float>), corrections without an exchange of their own, incl. a repeat
         g.flush(); one.flush()
-        plan = [3, 639, 200, 3, 638, 77, 511, 512][:batch]
+        plan = [3, 640, 200, 3, 639, 77, 511, 512][:batch]
         g.prefetch_rows(sorted(set(plan)))
         for idx0 in plan:
             step(idx0, False)
