@@ -200,12 +200,27 @@ int32_t refresh_work(ekf_handle *h) {
                     if (h->st.tm.mine(I, J)) sp.tiles.push_back(make_int2((int)I, (int)J));
             if (!sp.tiles.empty()) supers.push_back(std::move(sp));
         }
-    std::stable_sort(supers.begin(), supers.end(), [](const Super &a, const Super &b) { return a.tiles.size() > b.tiles.size(); });
+    // Order of the streams.  1 (default): the super-tiles in row-major order (si, then sj), flattened tile by tile and cut into 8
+    // equal contiguous runs -- an XCD walks along a band of S tile rows, so the band's K slice (S x 64 KiB at 32 pairs) stays in
+    // its L2 for the whole band and only the G slice changes from one super-tile to the next; runs are equal to within one tile.
+    // 0: round 1's schedule (largest super-tile first onto the least loaded stream): every super-tile fetched both slices anew
+    // and the streams differed by up to a super-tile (profiles/round2_tuning.md).
+    static const int order = [] { const char *v = getenv("EKF_XCD_ORDER"); return v ? atoi(v) : 1; }();
     std::vector<int2> stream[8];
-    for (const Super &sp : supers) {
-        int best = 0;
-        for (int x = 1; x < 8; ++x) if (stream[x].size() < stream[best].size()) best = x;
-        stream[best].insert(stream[best].end(), sp.tiles.begin(), sp.tiles.end());
+    if (order == 0) {
+        std::stable_sort(supers.begin(), supers.end(), [](const Super &a, const Super &b) { return a.tiles.size() > b.tiles.size(); });
+        for (const Super &sp : supers) {
+            int best = 0;
+            for (int x = 1; x < 8; ++x) if (stream[x].size() < stream[best].size()) best = x;
+            stream[best].insert(stream[best].end(), sp.tiles.begin(), sp.tiles.end());
+        }
+    } else {
+        std::vector<int2> flat_order;
+        flat_order.reserve(w.size());
+        for (const Super &sp : supers) flat_order.insert(flat_order.end(), sp.tiles.begin(), sp.tiles.end());
+        const size_t tot = flat_order.size();
+        for (int x = 0; x < 8; ++x)
+            stream[x].assign(flat_order.begin() + (tot * x) / 8, flat_order.begin() + (tot * (x + 1)) / 8);
     }
     size_t len = 0;
     for (int x = 0; x < 8; ++x) len = std::max(len, stream[x].size());

@@ -1419,8 +1419,11 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
                 tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
             }
         };
+#ifndef EKF_FLUSH_ABLATE
+#define EKF_FLUSH_ABLATE 0          // probes only (scripts/ab_flush.sh): 1 = no MFMA loop, 3 = no operand staging either (tile stream alone)
+#endif
         fetch(0, npairs < kChunk ? npairs : kChunk);
-        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+        for (int c0 = 0; c0 < ((EKF_FLUSH_ABLATE & 2) ? 0 : npairs); c0 += kChunk) {
             const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
             __syncthreads();                                          // everyone is done with the previous chunk
 #pragma unroll
@@ -1437,7 +1440,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
             }
             __syncthreads();
             if (c0 + kChunk < npairs) fetch(c0 + kChunk, npairs - c0 - kChunk < kChunk ? npairs - c0 - kChunk : kChunk);
-            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
+            const int ksteps = (EKF_FLUSH_ABLATE & 1) ? (Gs[0][tid & 127] == 1.2345e300 ? 1 : 0) : (cn + 1) >> 1;   // two pairs = four rank-1 terms per MFMA
 #pragma unroll 2
             for (int ks = 0; ks < ksteps; ++ks) {
                 const double a = Ks[4 * ks + lr][wave * 16 + lc];
@@ -1455,6 +1458,195 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
                         acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
                     }
             }
+        }
+#pragma unroll
+        for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < kE; ++e)
+                    __builtin_nontemporal_store((TS)acc[bp][e][r], td + (int64_t)(4 * r) * T + 16 * kE * bp + e);
+    }
+}
+
+// Batched flush, pipelined form (round 2) -- same arithmetic, same bits as k_flush_mfma; what changes is WHO waits for WHAT.
+// In k_flush_mfma the four wavefronts of a workgroup load their tile slab, then run the chunk loop (stage operands -> barrier ->
+// MFMA), then store: while they are in the matrix phase they have no tile traffic in flight, and a tile prefetch in registers
+// was blocked by the operand fetches of the later chunks queuing BEHIND it (vector-memory results return in order per
+// wavefront).  Measured (profiles/round2_tuning.md): tile stream alone 0.55 ms, matrix work alone 0.36 ms, together 0.61 ms.
+// Here the two kinds of traffic are issued by different wavefronts:
+//   * wavefront 4 (the STAGER) streams the pending (K, G) operands of every chunk global -> registers -> LDS, one chunk ahead of
+//     the matrix wavefronts, into a double-buffered operand image;
+//   * wavefronts 0-3 (MATRIX) own 16 rows x 128 columns each; their vector-memory queue carries only tile loads and stores, so
+//     the NEXT work item's slab is requested before the current item's MFMA loop and lands behind it.
+// A workgroup is persistent: it walks every nwg-th item of its XCD's stream.  One raw s_barrier per chunk (LDS visibility by
+// lgkmcnt(0) on the writer's side); no __syncthreads(), whose fence would drain the prefetch.
+struct FlushItem { int2 ij; int slab, cpart; };
+
+template <typename TS, int T, int kChunk, int kStagers>
+__global__ __launch_bounds__(256 + 64 * kStagers)
+void k_flush_pipe(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
+                  const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
+                  int npairs, TileMap tm) {
+    constexpr int kRows = 64, kCols = 128, kKPad = kRows + 16;
+    constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
+    constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
+    constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
+    static_assert(kBP * kE == 8 && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 columns = 8 MFMA blocks");
+    static_assert(kChunk % 2 == 0, "whole MFMA k-steps");
+    __shared__ __attribute__((aligned(16))) double Gs[2][2 * kChunk][kCols];
+    __shared__ double Ks[2][2 * kChunk][kKPad];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xs = blockIdx.x & 7;                                    // stream == XCD (round-robin dispatch: a speed assumption only)
+    const int lb = blockIdx.x >> 3, nwg = gridDim.x >> 3;             // position among the workgroups walking this stream
+    const int2 *__restrict__ wk = work + (int64_t)xs * nwork;
+    // valid tiles of this stream (padding (-1,-1) only at its end): uniform binary search
+    int lo = 0, hi = (int)nwork;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (wk[mid].x >= 0) lo = mid + 1; else hi = mid; }
+    const int nvalid = lo * kSubsPerTile;
+    const int nitems = lb < nvalid ? (nvalid - lb + nwg - 1) / nwg : 0;
+    const int nchunks = (npairs + kChunk - 1) / kChunk;
+    auto item_at = [&](int k) {
+        const int vi = lb + k * nwg;
+        const int w = vi / kSubsPerTile, sub = vi - w * kSubsPerTile;
+        FlushItem it;
+        it.ij = wk[w];
+        it.slab = sub / kColParts; it.cpart = sub - it.slab * kColParts;
+        return it;
+    };
+#ifndef EKF_PIPE_ABLATE
+#define EKF_PIPE_ABLATE 0           // probes only: 1 = no MFMA, 2 = stager idle, 4 = no barriers
+#endif
+    auto chunk_barrier = [] { if (!(EKF_PIPE_ABLATE & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if (nitems == 0) return;                                          // uniform per workgroup: no barrier is left unmatched
+
+    if (wave >= 4) {
+        // ------------------------------------------------ STAGER ------------------------------------------------
+        // kStagers wavefronts take the chunks round-robin (stager t: chunks q = t mod kStagers): a chunk's operands are requested
+        // kStagers chunk periods before they are written to LDS -- one period does not cover an L2 round trip under full HBM
+        // load (measured: 0.96 ms per pass with one stager, the matrix wavefronts waiting at every chunk barrier)
+        const int me = wave - 4;
+        constexpr int kPerG = kChunk * kCols / 64, kPerK = kChunk * kRows / 64;     // double2 per lane and chunk
+        static_assert(kCols == 128 && kRows == 64, "the stager's index arithmetic below is written for 128 columns x 64 rows");
+        // Everything but the lane offset is wave-uniform and most of it compile-time: register j of a lane holds pair (j >> 1),
+        // column lane + 64 (j & 1) of G, and pair j, row lane of K.  One wavefront must stage a chunk in less than the matrix
+        // wavefronts' 2048 MFMA cycles on it -- with per-element index arithmetic and predicated writes it took ~2.4 us, and the
+        // whole pass ran at the stager's pace (0.96 ms).
+        double2 rg[kPerG], rk[kPerK];
+        const int64_t ps2 = pair_stride >> 1;                         // slot stride in double2
+        auto load_chunk = [&](int q) {
+            const int k = q / nchunks, c0 = (q - k * nchunks) * kChunk;
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            const FlushItem it = item_at(k);
+            const double2 *__restrict__ gb = reinterpret_cast<const double2 *>(Gp) + ((int64_t)it.ij.y * T + it.cpart * kCols) + lane;
+            const double2 *__restrict__ kb = reinterpret_cast<const double2 *>(Kp) + ((int64_t)it.ij.x * T + it.slab * kRows) + lane;
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                const int ii = i < cn ? i : cn - 1;                   // clamp: always a valid pair, written only if in range
+                const int64_t so = (int64_t)ring_slot(pstart, c0 + ii, pcap) * ps2;      // scalar
+                rg[2 * i] = gb[so]; rg[2 * i + 1] = gb[so + 64];
+                rk[i] = kb[so];
+            }
+        };
+        auto write_chunk = [&](int q) {
+            const int k = q / nchunks, c0 = (q - k * nchunks) * kChunk;
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            double *__restrict__ gd = &Gs[q & 1][0][lane];
+            double *__restrict__ kd = &Ks[q & 1][0][lane];
+            if (cn == kChunk) {                                       // a full chunk: straight-line stores at immediate offsets
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    gd[(2 * i) * kCols] = rg[2 * i].x;          gd[(2 * i + 1) * kCols] = rg[2 * i].y;
+                    gd[(2 * i) * kCols + 64] = rg[2 * i + 1].x; gd[(2 * i + 1) * kCols + 64] = rg[2 * i + 1].y;
+                    kd[(2 * i) * kKPad] = -rk[i].x;             kd[(2 * i + 1) * kKPad] = -rk[i].y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    if (i < cn) {
+                        gd[(2 * i) * kCols] = rg[2 * i].x;          gd[(2 * i + 1) * kCols] = rg[2 * i].y;
+                        gd[(2 * i) * kCols + 64] = rg[2 * i + 1].x; gd[(2 * i + 1) * kCols + 64] = rg[2 * i + 1].y;
+                        kd[(2 * i) * kKPad] = -rk[i].x;             kd[(2 * i + 1) * kKPad] = -rk[i].y;
+                    } else if (i == cn) {                             // pad of an odd count: A = -0.0, B = +0.0
+                        gd[(2 * i) * kCols] = 0.0;      gd[(2 * i + 1) * kCols] = 0.0;
+                        gd[(2 * i) * kCols + 64] = 0.0; gd[(2 * i + 1) * kCols + 64] = 0.0;
+                        kd[(2 * i) * kKPad] = -0.0;     kd[(2 * i + 1) * kKPad] = -0.0;
+                    }
+                }
+            }
+        };
+        const int Q = nitems * nchunks;
+        // my chunks: me, me + kStagers, ...; `mine` = the next one I have to write, its operands already requested
+        int mine = me;
+        if (mine < Q) load_chunk(mine);
+        if (me == 0) { write_chunk(0); mine += kStagers; if (mine < Q) load_chunk(mine); }
+        chunk_barrier();                                              // #0: chunk 0 visible
+        for (int q = 0; q < Q; ++q) {
+            // the matrix wavefronts are on chunk q (buffer q & 1); buffer (q + 1) & 1 was released by barrier #q
+            if (q + 1 == mine && !(EKF_PIPE_ABLATE & 2)) {
+                write_chunk(mine);
+                mine += kStagers;
+                if (mine < Q) load_chunk(mine);
+            }
+            chunk_barrier();                                          // #(q+1): chunk q + 1 visible, buffer q & 1 free
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- MATRIX ----------------------------------------------------
+    const int lr = lane >> 4, lc = lane & 15;                         // MFMA k / row-group index, MFMA row / column index
+    auto slab_offset = [&](const FlushItem &it) {
+        return tm.tile_offset(it.ij.x, it.ij.y) + (int64_t)(it.slab * kRows + wave * 16 + lr) * T + it.cpart * kCols + kE * lc;
+    };
+    TS nxt[kBP][4][kE];                                               // the NEXT item's slab, in flight behind this item's MFMA loop
+    auto request = [&](int k) {
+        const TS *__restrict__ tp = tiles + slab_offset(item_at(k));
+#pragma unroll
+        for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < kE; ++e)                          // adjacent scalars: one 16-byte nontemporal load
+                    nxt[bp][r][e] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 16 * kE * bp + e);
+    };
+    request(0);
+    chunk_barrier();                                                  // #0
+    int q = 0;
+    for (int k = 0; k < nitems; ++k) {
+        d4_t acc[kBP][kE];                                            // [16-byte group bp][column e in it][row r -> +4r]
+#pragma unroll
+        for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < kE; ++e) acc[bp][e][r] = (double)nxt[bp][r][e];
+        TS *__restrict__ td = dst + slab_offset(item_at(k));
+        if (k + 1 < nitems) request(k + 1);
+        for (int c = 0; c < nchunks; ++c, ++q) {
+            const int c0 = c * kChunk;
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            const int b = q & 1;
+            const int ksteps = (EKF_PIPE_ABLATE & 1) ? (Gs[0][0][lane] == 1.2345e300 ? 1 : 0) : (cn + 1) >> 1;   // two pairs = four rank-1 terms per MFMA
+#pragma unroll 2
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const double a = Ks[b][4 * ks + lr][wave * 16 + lc];
+                double2 bv[kBP][kE / 2];
+#pragma unroll
+                for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+                    for (int h = 0; h < kE / 2; ++h)
+                        bv[bp][h] = *reinterpret_cast<const double2 *>(&Gs[b][4 * ks + lr][16 * kE * bp + kE * lc + 2 * h]);
+#pragma unroll
+                for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+                    for (int h = 0; h < kE / 2; ++h) {
+                        acc[bp][2 * h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].x, acc[bp][2 * h], 0, 0, 0);
+                        acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
+                    }
+            }
+            chunk_barrier();                                          // #(q+1): done reading buffer b; chunk q + 1 visible
         }
 #pragma unroll
         for (int bp = 0; bp < kBP; ++bp)
@@ -1486,6 +1678,27 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;
         if (!use_mfma || npairs < kMinPairs || !work_xcd || xcd_len <= 0) return false;
         constexpr int kSubs = (T / 64) * (T / 128);
+        // pipelined form (k_flush_pipe): persistent workgroups, stager + matrix wavefronts; EKF_FLUSH_PIPE=0 -> round 1's kernel,
+        // EKF_FLUSH_PIPE_WGS = workgroups per CU (default 2 = what its registers and LDS allow)
+        static const int use_pipe = [] { const char *v = getenv("EKF_FLUSH_PIPE"); return v ? atoi(v) : 1; }();
+        static const int pipe_min = [] { const char *v = getenv("EKF_FLUSH_PIPE_MIN"); return v ? atoi(v) : 2; }();
+        if (use_pipe && npairs >= pipe_min) {
+            static const int wgs_per_cu = [] { const char *v = getenv("EKF_FLUSH_PIPE_WGS"); const int x = v ? atoi(v) : 2; return x < 1 ? 1 : x; }();
+            int ncu = 256;
+            { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount; }
+            int64_t grid = (int64_t)ncu * wgs_per_cu;
+            grid -= grid % 8;                                          // whole sets of 8: workgroup b walks stream b % 8
+            if (grid < 8) grid = 8;
+            const int64_t most = 8 * xcd_len * kSubs;
+            if (grid > most) grid = most - most % 8 > 0 ? most - most % 8 : 8;
+            static const int stagers = [] { const char *v = getenv("EKF_FLUSH_PIPE_STAGERS"); return v ? atoi(v) : 2; }();
+#define EKF_PIPE(NS) hipLaunchKernelGGL((k_flush_pipe<TS, T, 8, NS>), dim3((unsigned)grid), dim3(256 + 64 * NS), 0, s, (const TS *)st.tiles, \
+                                        (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm)
+            if (stagers <= 1) EKF_PIPE(1); else if (stagers == 2) EKF_PIPE(2); else if (stagers == 3) EKF_PIPE(3); else EKF_PIPE(4);
+#undef EKF_PIPE
+            name_kernel(kname, "k_flush_pipe", sizeof(TS), T, 8, -1);
+            return true;
+        }
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if (npairs <= chunk_switch)
