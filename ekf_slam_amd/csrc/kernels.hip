@@ -105,36 +105,57 @@ struct PredictSmall { double fa, fb; double pose[3]; double prr[9]; double Q[9];
 // sin/cos/atan2 gave different last bits in different kernels).  They live in noinline wrappers -- ONE machine-code
 // body shared by every kernel -- so that the standalone predict, the predict folded into a correction and the
 // association kernel cannot differ by a rounding.  Everything else is plain IEEE arithmetic (-ffp-contract=off).
-__device__ __attribute__((noinline)) void sincosd_ni(double a, double &sn, double &cs) { ekfm::sincosd(a, sn, cs); }
+// (results by VALUE: reference parameters of a noinline function live on the stack, i.e. in scratch memory -- a global-memory
+//  round trip in the middle of the latency chain)
+__device__ __attribute__((noinline)) double2 sincosd_ni(double a) { double sn, cs; ekfm::sincosd(a, sn, cs); return make_double2(sn, cs); }
 __device__ __attribute__((noinline)) double bearing_ni(double d1, double d0, double th) {
     return ekfm::wrapTo360(ekfm::atan2d(d1, d0) - th);                                // EKF_SLAM.m:130
 }
 
-// predict, given sind/cosd of the pre-motion heading (sn, cs) and of heading + u2 (sn2, cs2)
+// Per-entry forms of predict: ONE definition of every expression, used by the serial composition below (k_predict, one lane)
+// and by the lane-parallel one in k_gather (one entry per lane) -- so the two cannot differ by a rounding.
+// F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64); W = [u1 cosd th; u1 sind th; u2] (EKF_SLAM.m:42)
+__device__ __forceinline__ void predict_common(double u0, double u1, double sn, double cs, double &fa, double &fb, double W[3]) {
+    fa = -1 * u0 * sn;
+    fb = u0 * cs;
+    W[0] = u0 * cs; W[1] = u0 * sn; W[2] = u1;
+}
+// (F*P)(i,c) for the 3x3 robot block: rows 1, 2 pick up F(.,3) * P(3,c)
+__device__ __forceinline__ double predict_fp(const double *prr, int i, int c, double fa, double fb) {
+    return i == 0 ? prr[c] + fa * prr[6 + c] : i == 1 ? prr[3 + c] + fb * prr[6 + c] : prr[6 + c];
+}
+// entry (i,j) of F*Prr*F' + Q and of Q = (W*C)*W'  (EKF_SLAM.m:44,47)
+// (wi, wj = W(i), W(j): passed by value so that a lane-parallel caller selects them instead of indexing a register array)
+__device__ __forceinline__ void predict_prr_entry(const double *prr, int i, int j, double fa, double fb, double wi, double wj, double C,
+                                                  double &out, double &q) {
+    const double m1 = predict_fp(prr, i, j, fa, fb), p2 = predict_fp(prr, i, 2, fa, fb);
+    const double m2 = j == 0 ? m1 + fa * p2 : j == 1 ? m1 + fb * p2 : m1;                   // (F*P)*F'
+    q = (wi * C) * wj;
+    out = m2 + q;
+}
+// new pose entry i  (EKF_SLAM.m:58-60,50)
+__device__ __forceinline__ double predict_pose_entry(const double pose[3], int i, double u0, double u1, double sn2, double cs2) {
+    return i == 0 ? pose[0] + u0 * cs2 : i == 1 ? pose[1] + u0 * sn2 : ekfm::wrapTo360(pose[2] + u1);
+}
+
+// predict, given sind/cosd of the pre-motion heading (sn, cs) and of heading + u2 (sn2, cs2): serial composition
 __device__ __forceinline__ void predict_finish(const double pose[3], const double prr_in[9], double u0, double u1, double C,
                                                double sn, double cs, double sn2, double cs2, PredictSmall &o) {
-    const double th = pose[2];
-    // F(1,3), F(2,3) use the PRE-motion heading, no pi/180 (EKF_SLAM.m:63-64)
-    o.fa = -1 * u0 * sn;
-    o.fb = u0 * cs;
-    const double W[3] = { u0 * cs, u0 * sn, u1 };                                     // EKF_SLAM.m:42
+    double W[3];
+    predict_common(u0, u1, sn, cs, o.fa, o.fb, W);
+#pragma unroll
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) o.Q[3 * i + j] = (W[i] * C) * W[j];              // EKF_SLAM.m:44
-    double M[9];
-    for (int i = 0; i < 9; ++i) M[i] = prr_in[i];
-    for (int j = 0; j < 3; ++j) { const double p2 = M[6 + j]; M[j] += o.fa * p2; M[3 + j] += o.fb * p2; }          // F*P
-    for (int i = 0; i < 3; ++i) { const double p2 = M[3 * i + 2]; M[3 * i] += o.fa * p2; M[3 * i + 1] += o.fb * p2; }  // *F'
-    for (int i = 0; i < 9; ++i) o.prr[i] = M[i] + o.Q[i];
-    o.pose[0] = pose[0] + u0 * cs2;                                                   // EKF_SLAM.m:58-60
-    o.pose[1] = pose[1] + u0 * sn2;
-    o.pose[2] = ekfm::wrapTo360(th + u1);                                             // EKF_SLAM.m:50
+#pragma unroll
+        for (int j = 0; j < 3; ++j) predict_prr_entry(prr_in, i, j, o.fa, o.fb, W[i], W[j], C, o.prr[3 * i + j], o.Q[3 * i + j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o.pose[i] = predict_pose_entry(pose, i, u0, u1, sn2, cs2);
 }
 
 __device__ __forceinline__ void predict_small(const double pose[3], const double prr_in[9], double u0, double u1, double C,
                                               PredictSmall &o) {
     double sn, cs, sn2, cs2;
-    sincosd_ni(pose[2], sn, cs);
-    sincosd_ni(pose[2] + u1, sn2, cs2);
+    const double2 sc = sincosd_ni(pose[2]), sc2 = sincosd_ni(pose[2] + u1);
+    sn = sc.x; cs = sc.y; sn2 = sc2.x; cs2 = sc2.y;
     predict_finish(pose, prr_in, u0, u1, C, sn, cs, sn2, cs2, o);
 }
 
@@ -299,34 +320,49 @@ __device__ __forceinline__ void solve_hs(double d0, double d1, double &sq, doubl
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 5; ++b) Hs[a][b] = iq * e[a][b];
 }
 
+// Per-entry forms of the small solve (same idea as predict_*_entry above).  h / g are ROWS of H_s / G(:,S), so that a lane-parallel
+// caller can select its row without indexing a register array dynamically (that would put the array in scratch memory);
+// `pss` may be a register array (serial callers, static b) or the LDS copy (lane-parallel caller, b = f(lane)).
+// G(a, S(b)) = H_s(a,:) * P(S, S(b))  (EKF_SLAM.m:141, first product); b < 3: robot columns (P(j+t, b) is stored as
+// strip(b, j+t)), b >= 3: columns j, j+1
+__device__ __forceinline__ double solve_gs_entry(const double *pss, const double h[5], int b) {
+    double acc = 0;
+    if (b < 3) {
+        for (int t = 0; t < 3; ++t) acc += h[t] * pss[3 * t + b];
+        for (int t = 0; t < 2; ++t) acc += h[3 + t] * pss[9 + 2 * b + t];
+    } else {
+        for (int t = 0; t < 3; ++t) acc += h[t] * pss[9 + 2 * t + (b - 3)];
+        for (int t = 0; t < 2; ++t) acc += h[3 + t] * pss[15 + 2 * t + (b - 3)];
+    }
+    return acc;
+}
+// phi(a,b) = G(a,S) * H_s(b,:)' + R(a,b)  (EKF_SLAM.m:141)
+__device__ __forceinline__ double solve_phi_entry(const double g[5], const double h[5], double Rab) {
+    double acc = 0;
+    for (int t = 0; t < 5; ++t) acc += g[t] * h[t];
+    return acc + Rab;
+}
+// K_r(b,cc) = G_r(:,b)' * inv(phi)(:,cc)
+__device__ __forceinline__ double solve_kr_entry(double g0b, double g1b, double phi_c, double phi_2c) {
+    return g0b * phi_c + g1b * phi_2c;
+}
+
 // everything after H_s and the predicted measurement (zhat0 = range, zhat1 = bearing): G(:,S), phi, inv(phi), nu, K_r
 __device__ __forceinline__ void solve_rest(const double *pss, double zhat0, double zhat1, double z0, double z1, double R00,
                                            double R01, double R10, double R11, SmallSolve &o) {
     double GS[2][5];
-    for (int a = 0; a < 2; ++a) {
-        for (int b = 0; b < 3; ++b) {      // robot columns: P(j+t, b) is stored as strip(b, j+t)
-            double acc = 0;
-            for (int t = 0; t < 3; ++t) acc += o.Hs[a][t] * pss[3 * t + b];
-            for (int t = 0; t < 2; ++t) acc += o.Hs[a][3 + t] * pss[9 + 2 * b + t];
-            GS[a][b] = acc; o.Gr[a][b] = acc;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 5; ++b) {
+            GS[a][b] = solve_gs_entry(pss, o.Hs[a], b);
+            if (b < 3) o.Gr[a][b] = GS[a][b];
         }
-        for (int b = 0; b < 2; ++b) {      // columns j, j+1
-            double acc = 0;
-            for (int t = 0; t < 3; ++t) acc += o.Hs[a][t] * pss[9 + 2 * t + b];
-            for (int t = 0; t < 2; ++t) acc += o.Hs[a][3 + t] * pss[15 + 2 * t + b];
-            GS[a][3 + b] = acc;
-        }
-    }
     const double R[2][2] = { { R00, R01 }, { R10, R11 } };
     double phi[4];
-    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {                          // :141
-        double acc = 0; for (int t = 0; t < 5; ++t) acc += GS[a][t] * o.Hs[b][t];
-        phi[2 * a + b] = acc + R[a][b]; }
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) phi[2 * a + b] = solve_phi_entry(GS[a], o.Hs[b], R[a][b]);   // :141
     ekfm::inv2(phi, o.Phi);                                                            // :143 phi_k^-1
     o.nu[0] = z0 - zhat0;                                                              // :144 (bearing NOT wrapped)
     o.nu[1] = z1 - zhat1;
-    for (int b = 0; b < 3; ++b) for (int cc = 0; cc < 2; ++cc)
-        o.Kr[b][cc] = o.Gr[0][b] * o.Phi[cc] + o.Gr[1][b] * o.Phi[2 + cc];
+    for (int b = 0; b < 3; ++b) for (int cc = 0; cc < 2; ++cc) o.Kr[b][cc] = solve_kr_entry(o.Gr[0][b], o.Gr[1][b], o.Phi[cc], o.Phi[2 + cc]);
 }
 
 // serial composition (association kernel: one lane per landmark)
@@ -453,13 +489,36 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel_base(DevState st, RowList r
     reinterpret_cast<double2 *>(send + (int64_t)q * slab)[e] = make_double2(m0, m1);
 }
 
+// Workgroup layout of k_gather: 256 column lanes (wavefronts 0-3) + three helper wavefronts that own no column:
+//   wavefront 4  CHAIN     the small solve, one matrix ENTRY per lane (predict's 3x3, H_s, the 2x5 / 2x2 products, K_r)
+//   wavefront 5  DIAG      the pending pairs on the landmark's own 2x2 block (a chain in slot order: inherently serial)
+//   wavefront 6  BEARING   sincos of the new heading, atan2, the innovation nu
+// Round 1 ran the whole solve on ONE lane of wavefront 0 (~400 dependent f64 operations, 4 700 clocks) behind a barrier that
+// also waited for every column lane's loads and patches.  Now the solve depends only on the 24 small operands; the helpers
+// meet the column lanes at ONE barrier, when K_r, H_s, inv(phi) and nu are in LDS.
+constexpr int kGatherCols = 256;
+constexpr int kGatherBlock = kGatherCols + 3 * 64;
+
+__device__ __forceinline__ double lane_bcast(double v, int src) {        // value of lane `src` (compile-time) on every lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// LDS traffic of ONE wavefront is ordered; this only keeps the compiler from moving accesses across it and drains the queue
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <typename TS, bool kSharded, bool kPredict>
-__global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
+__global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
     __shared__ PredictSmall ps;
+    __shared__ double gs_sh[10], phi_sh[4];
+    __shared__ double pose_sh[3];                   // the pose the correction starts from (predicted when predict is folded in);
+                                                    // pss[19..21] keep the BASE pose: the BEARING wavefront reads it concurrently
+    __shared__ int diag_ready;
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const int tid = threadIdx.x;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3 columns, 4 chain, 5 diag, 6 bearing
+    const int lane = tid & 63;
     const int cur = a.cur;
     // double-buffered state: both pointers of a pair arrive with the first kernel-argument fetch and are SELECTED (indexing the
     // by-value struct with `cur` makes the compiler fetch the pointer with a second, dependent scalar load)
@@ -483,7 +542,6 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
                      "s"(a.pstart));
     }
     const bool do_patch = !kSharded || !pv.patched;       // base values in hand: apply the pending pairs here
-    const int64_t c = (int64_t)blockIdx.x * kBlock + tid;
 #ifdef EKF_GATHER_STAMPS
     long long stamp[12]; int nst = 0;
 #define EKF_STAMP() do { stamp[nst++] = clock64(); } while (0)
@@ -491,39 +549,181 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 #else
 #define EKF_STAMP() do { } while (0)
 #endif
-    const bool live = c < a.n_mm;
 
-    // (1) Loads, in the order their consumers need them.  Vector-memory results return in order, so what gates the scalar
-    //     prologue is requested FIRST: the 5x5 sub-block P(S,S), the pose, the landmark (24 doubles, one per thread) and the
-    //     wave-uniform operands of the pending pairs (K_i / G_i at rows / columns j, j+1).
+    if (role >= 4) {
+        // =========================================== helper wavefronts ===========================================
+        // (1h) the 5x5 sub-block P(S,S), the pose, the landmark: 24 doubles, one per lane of the CHAIN wavefront (unconditional
+        //      selected addresses, see the column path)
+        if (role == 4) {
+            const double *sp = prr_cur;                                  // lanes >= 24 re-read Prr(1,1), unused
+            if (lane < 9) sp = prr_cur + lane;
+            else if (lane < 15) { const int t = (lane - 9) >> 1, b = (lane - 9) & 1; sp = strip + t * ldm + j + b; }
+            else if (lane >= 19 && lane < 22) sp = x + (lane - 19);
+            else if (lane >= 22 && lane < 24) sp = x + 3 + j + (lane - 22);
+            double small_v = *sp;
+            if (lane >= 15 && lane < 19) {
+                const int t = (lane - 15) >> 1, b = (lane - 15) & 1;     // canonical P(j+t, j+b)
+                if (kSharded) {
+                    const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
+                    small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
+                } else {
+                    // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
+                    const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
+                    const int rr = t > b ? t : b, cc2 = t > b ? b : t;
+                    small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
+                }
+            }
+            if (lane < 24) pss[lane] = small_v;
+            if (lane == 24) diag_ready = 0;
+        }
+        EKF_STAMP();                                                  // 1: small operands requested / staged
+        __syncthreads();                                              // barrier A: pss (base values) and upatch staged
+        EKF_STAMP();                                                  // 2
+        if (role == 5) {
+            // ---- DIAG: canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so
+            //      that the LDS latency is paid per group, not per pair
+            if (do_patch && npend > 0) {
+                if (lane < 3) {
+                    const int q = lane;
+                    const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
+                    double d = pss[q == 0 ? 15 : q == 1 ? 17 : 18];
+                    for (int i0 = 0; i0 < npend; i0 += 8) {
+                        double2 kk[8], gg[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const int ii = i0 + t < npend ? i0 + t : npend - 1;       // clamp: stay inside the staged entries
+                            kk[t] = upatch[4 * ii + ka]; gg[t] = upatch[4 * ii + ga];
+                        }
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) { const double v = rank2_apply(d, kk[t], gg[t]); d = i0 + t < npend ? v : d; }
+                    }
+                    if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
+                }
+                wave_lds_sync();                                          // the patched block is written ...
+                if (lane == 0) *(volatile int *)&diag_ready = 1;          // ... before the flag (one wavefront: LDS order = program order)
+            }
+        } else if (role == 6) {
+            // ---- BEARING: nu = z - z_k, z_k = [sqrt(q); wrapTo360(atan2d(dy,dx) - heading)]  (EKF_SLAM.m:125-130,144), from the
+            //      PREDICTED pose when predict is folded in -- same expressions as the chain wavefront's, so the same bits
+            if (lane == 0) {
+                double pose[3] = { pss[19], pss[20], pss[21] };
+                if (kPredict) {
+                    const double2 sc2 = sincosd_ni(pose[2] + pa.u1);
+                    const double sn2 = sc2.x, cs2 = sc2.y;
+                    const double p0 = predict_pose_entry(pose, 0, pa.u0, pa.u1, sn2, cs2), p1 = predict_pose_entry(pose, 1, pa.u0, pa.u1, sn2, cs2),
+                                 p2 = predict_pose_entry(pose, 2, pa.u0, pa.u1, sn2, cs2);
+                    pose[0] = p0; pose[1] = p1; pose[2] = p2;
+                }
+                const double d0 = pss[22] - pose[0], d1 = pss[23] - pose[1];
+                const double bearing = bearing_ni(d1, d0, pose[2]);
+                const double sq = sqrt(d0 * d0 + d1 * d1);
+                sol.nu[0] = a.z0 - sq;                                    // :144 (bearing NOT wrapped)
+                sol.nu[1] = a.z1 - bearing;
+            }
+        } else {
+            // ---- CHAIN: each matrix entry of the solve is formed on its own lane.  Operands whose index depends on the lane are read
+            //      from the LDS copy `pss` (a register array indexed by the lane would live in scratch memory); what every lane
+            //      needs identically (pose, landmark, H_s, inv(phi)) is computed redundantly in registers.
+            double fa = 0.0, fb = 0.0;
+            double pose[3] = { pss[19], pss[20], pss[21] };
+            const double lmx = pss[22], lmy = pss[23];
+            if (kPredict) {
+                // predict(u) folded into this correction: same per-entry arithmetic as k_predict (predict_*_entry)
+                const double2 sc_l = sincosd_ni((lane & 1) ? pose[2] + pa.u1 : pose[2]);   // lane 0: pre-motion heading, lane 1: + u2
+                const double sn = lane_bcast(sc_l.x, 0), cs = lane_bcast(sc_l.y, 0), sn2 = lane_bcast(sc_l.x, 1), cs2 = lane_bcast(sc_l.y, 1);
+                double W[3];
+                predict_common(pa.u0, pa.u1, sn, cs, fa, fb, W);
+                double mine = 0.0, myq = 0.0;                         // lane l: l < 9 Prr'(l/3, l%3) and Q; 9..14 strip'(t, j+b)
+                if (lane < 9) {
+                    const int ei = lane / 3, ej = lane - 3 * ei;
+                    const double wi = ei == 0 ? W[0] : ei == 1 ? W[1] : W[2], wj = ej == 0 ? W[0] : ej == 1 ? W[1] : W[2];
+                    predict_prr_entry(pss, ei, ej, fa, fb, wi, wj, pa.C, mine, myq);
+                }
+                else if (lane < 15) {
+                    const int t = (lane - 9) >> 1, b = (lane - 9) & 1;
+                    double s0 = pss[9 + b], s1 = pss[11 + b];
+                    const double s2 = pss[13 + b];
+                    predict_strip(s0, s1, s2, fa, fb);
+                    mine = t == 0 ? s0 : t == 1 ? s1 : s2;
+                }
+                const double p0 = predict_pose_entry(pose, 0, pa.u0, pa.u1, sn2, cs2), p1 = predict_pose_entry(pose, 1, pa.u0, pa.u1, sn2, cs2),
+                             p2 = predict_pose_entry(pose, 2, pa.u0, pa.u1, sn2, cs2);      // every lane (3 operations)
+                pose[0] = p0; pose[1] = p1; pose[2] = p2;
+                wave_lds_sync();                                      // every lane has READ its operands ...
+                if (lane < 15) pss[lane] = mine;                      // ... before anyone overwrites them; the column lanes read Prr'
+                if (lane < 9) ps.Q[lane] = myq;                       // and strip' from here
+                if (lane == 0) { ps.fa = fa; ps.fb = fb; }
+                wave_lds_sync();
+            }
+            if (lane < 3) pose_sh[lane] = lane == 0 ? pose[0] : lane == 1 ? pose[1] : pose[2];
+            EKF_STAMP();                                              // 3: predict entries exchanged
+            SmallSolve so;
+            double sq;
+            solve_hs(lmx - pose[0], lmy - pose[1], sq, so.Hs);        // EKF_SLAM.m:125-127,137-138 (every lane, redundantly)
+            if (do_patch && npend > 0) {
+                while (*(volatile int *)&diag_ready == 0) { }         // the DIAG wavefront's patched 2x2 block is in pss[15..18]
+                wave_lds_sync();
+            }
+            const int ra = lane >= 5 ? 1 : 0;                         // row of this lane's G(:,S) entry
+            double hsel[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) hsel[t] = ra ? so.Hs[1][t] : so.Hs[0][t];
+            if (lane < 10) gs_sh[lane] = solve_gs_entry(pss, hsel, lane - 5 * ra);
+            wave_lds_sync();
+            double GS[2][5];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) GS[i / 5][i % 5] = gs_sh[i];
+            {
+                const int aa = (lane >> 1) & 1, bb = lane & 1;
+                double gsel[5], hb[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) { gsel[t] = aa ? GS[1][t] : GS[0][t]; hb[t] = bb ? so.Hs[1][t] : so.Hs[0][t]; }
+                const double Rab = aa == 0 ? (bb == 0 ? a.R00 : a.R01) : (bb == 0 ? a.R10 : a.R11);
+                if (lane < 4) phi_sh[lane] = solve_phi_entry(gsel, hb, Rab);                // :141
+            }
+            wave_lds_sync();
+            double phi[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) phi[i] = phi_sh[i];
+            ekfm::inv2(phi, so.Phi);                                  // :143 phi_k^-1 (every lane, redundantly)
+            EKF_STAMP();                                              // 4: solve
+            // publish: H_s and inv(phi) from lane 0 (static indices), K_r and G_r one entry per lane (operands by LDS index)
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) sol.Hs[i / 5][i % 5] = so.Hs[i / 5][i % 5];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sol.Phi[i] = so.Phi[i];
+            } else if (lane >= 14 && lane < 20) {
+                const int b = (lane - 14) >> 1, cc = (lane - 14) & 1;
+                sol.Kr[b][cc] = solve_kr_entry(gs_sh[b], gs_sh[5 + b], cc ? so.Phi[1] : so.Phi[0], cc ? so.Phi[3] : so.Phi[2]);
+            } else if (lane >= 20 && lane < 26) {
+                const int aa = (lane - 20) >= 3 ? 1 : 0, b = (lane - 20) - 3 * aa;
+                sol.Gr[aa][b] = gs_sh[5 * aa + b];
+            }
+        }
+        __syncthreads();                                              // barrier B: sol, ps, pss complete
+#ifdef EKF_GATHER_STAMPS
+        EKF_STAMP();                                                  // 5
+        if (blockIdx.x == 0 && tid == kGatherCols) for (int i = 0; i < 6; ++i) st.small[21 + i] = (double)(stamp[i] - stamp[0]);
+#endif
+        return;
+    }
+
+    // ================================================ column lanes ================================================
+    const int64_t c = (int64_t)blockIdx.x * kGatherCols + tid;
+    const bool live = c < a.n_mm;
+    // (1) Loads, in the order their consumers need them.  Vector-memory results return in order, so the wave-uniform operands of
+    //     the pending pairs (K_i / G_i at rows / columns j, j+1), which the DIAG wavefront and everyone's patches need, go FIRST.
     //     Every load below is unconditional with a selected / clamped address: a predicated load is merged by the compiler
     //     with the predicated LDS write that consumes it, which puts a full memory round trip in front of everything else.
-    const double *sp = prr_cur;                                  // threads >= 24 re-read Prr(1,1), unused
-    if (tid < 9) sp = prr_cur + tid;
-    else if (tid < 15) { const int t = (tid - 9) >> 1, b = (tid - 9) & 1; sp = strip + t * ldm + j + b; }
-    else if (tid >= 19 && tid < 22) sp = x + (tid - 19);
-    else if (tid >= 22 && tid < 24) sp = x + 3 + j + (tid - 22);
-    double small_v = *sp;
-    if (tid >= 15 && tid < 19) {
-        const int t = (tid - 15) >> 1, b = (tid - 15) & 1;     // canonical P(j+t, j+b)
-        if (kSharded) {
-            const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
-            small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
-        } else {
-            // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
-            const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
-            const int rr = t > b ? t : b, cc2 = t > b ? b : t;
-            small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
-        }
-    }
-    static_assert(kMaxPending * 4 == 2 * kBlock, "two uniform operands per thread");
+    static_assert(kMaxPending * 4 == 2 * kGatherCols, "two uniform operands per column lane");
     auto load_up = [&](int e0) {
         const int e = (do_patch && e0 < 4 * npend) ? e0 : 0;     // clamped: slot pstart always exists
         const int i = e >> 2, which = e & 3;
         const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
         return reinterpret_cast<const double2 *>(base)[j + (which & 1)];
     };
-    const double2 up0 = load_up(tid), up1 = load_up(tid + kBlock);
+    const double2 up0 = load_up(tid), up1 = load_up(tid + kGatherCols);
     __builtin_amdgcn_sched_barrier(0);      // keep these loads AHEAD of the per-column ones below (in-order return)
     EKF_STAMP();                                                  // a: uniform operands requested
     //     Then what this column needs: the two landmark rows at column c (canonical lower-triangle entries: row part left of
@@ -585,40 +785,11 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
 
     EKF_STAMP();                                                  // b: all loads requested
     // (2) stage the uniform operands (waits for the FIRST group of loads only)
-    if (tid < 24) pss[tid] = small_v;
-    upatch[tid] = up0; upatch[tid + kBlock] = up1;                // unconditional too (entries past 4*npend are never read)
-    __syncthreads();
-    EKF_STAMP();                                                  // 1: small operands staged
+    upatch[tid] = up0; upatch[tid + kGatherCols] = up1;           // unconditional (entries past 4*npend are never read)
+    __syncthreads();                                              // barrier A
+    EKF_STAMP();                                                  // 1: uniform operands staged
 
-    // (3) the scalar prologue, spread over three wavefronts so that its independent pieces run side by side (they are
-    //     long chains of dependent f64 operations on ONE lane each):
-    //       wave 0: sind/cosd of the pre-motion heading      wave 1: sind/cosd of heading + u2
-    //       wave 2: the pending pairs on the 2x2 diagonal block
-    //     Meanwhile every lane applies the pending pairs to its own two row entries.  After the barrier lane 0 runs the
-    //     rest of the chain (predict, H_s, bearing, 2x2 solve) in one piece.
-    __shared__ double stage[4];          // sn, cs, sn2, cs2
-    if (kPredict) {
-        if (tid == 0) sincosd_ni(pss[21], stage[0], stage[1]);
-        if (tid == 64) sincosd_ni(pss[21] + pa.u1, stage[2], stage[3]);
-    }
-    if (do_patch && tid >= 128 && tid < 131) {
-        // canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so that
-        // the LDS latency is paid per group, not per pair (it was 200 clocks per pending pair on one lane)
-        const int q = tid - 128;
-        const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
-        double d = pss[q == 0 ? 15 : q == 1 ? 17 : 18];
-        for (int i0 = 0; i0 < npend; i0 += 8) {
-            double2 kk[8], gg[8];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int ii = i0 + t < npend ? i0 + t : npend - 1;       // clamp: stay inside the staged entries
-                kk[t] = upatch[4 * ii + ka]; gg[t] = upatch[4 * ii + ga];
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { const double v = rank2_apply(d, kk[t], gg[t]); d = i0 + t < npend ? v : d; }
-        }
-        if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
-    }
+    // (3) every lane applies the pending pairs to its own two row entries while the helper wavefronts run the solve
     if (live && do_patch) {
         if (rowpart) {
 #pragma unroll
@@ -688,44 +859,9 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
             }
         }
     }
-    __syncthreads();
-    EKF_STAMP();                                                  // 2: sincos + patches done
-    if (tid == 0) {
-        // One lane runs the rest of the scalar chain back to back on register copies: predict -> H_s -> bearing -> solve,
-        // ~400 dependent f64 operations = 4700 clocks (scripts/probe_gather_phases.py).  Three barrier-separated phases with
-        // the atan2 on a second wavefront took the same time (the barriers and LDS hops cost what the parallel atan2 saved);
-        // this form has two workgroup barriers less.  Only spreading the 2x5 / 3x3 products over lanes would shorten it.
-        double p[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) p[i] = pss[i];
-        // results are formed in registers and copied to LDS once (forming them in the LDS structs put an LDS round trip
-        // between dependent operations)
-        SmallSolve so;
-        if (kPredict) {
-            // predict(u) folded into this correction: same arithmetic as k_predict, applied to the staged values
-            PredictSmall po;
-            const double pose[3] = { p[19], p[20], p[21] };
-            predict_finish(pose, p, pa.u0, pa.u1, pa.C, stage[0], stage[1], stage[2], stage[3], po);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) p[i] = po.prr[i];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) predict_strip(p[9 + b], p[11 + b], p[13 + b], po.fa, po.fb);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) p[19 + i] = po.pose[i];
-#pragma unroll
-            for (int i = 0; i < 15; ++i) pss[i] = p[i];             // the output lanes read Prr and the pose from here
-#pragma unroll
-            for (int i = 19; i < 22; ++i) pss[i] = p[i];
-            ps = po;
-        }
-        double sq;
-        solve_hs(p[22] - p[19], p[23] - p[20], sq, so.Hs);                                // EKF_SLAM.m:125-127,137-138
-        const double bearing = bearing_ni(p[23] - p[20], p[22] - p[19], p[21]);
-        solve_rest(p, sq, bearing, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, so);
-        sol = so;
-    }
-    __syncthreads();
-    EKF_STAMP();                                                  // 5: solve
+    EKF_STAMP();                                                  // 2: patches done
+    __syncthreads();                                              // barrier B: the helpers' results are in LDS
+    EKF_STAMP();                                                  // 3: solve available
 
     // (4) the column's share of G, K, x and the strip
     const int64_t pad_end = st.tm.padded(a.n_mm);
@@ -754,7 +890,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
     if (blockIdx.x == 0 && tid < 33) {
         // the replicated small outputs, one entry per lane of workgroup 0 (they used to be ~35 dependent stores on one lane
         // at the tail of the kernel): x_r (x(3) NOT re-wrapped), Prr, and G_r / K_r / Q for the host-side getters
-        if (tid < 3) x_nxt[tid] = pss[19 + tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
+        if (tid < 3) x_nxt[tid] = pose_sh[tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
         else if (tid < 12) {
             const int r = (tid - 3) / 3, b = (tid - 3) - 3 * r;
             prr_nxt[3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
@@ -764,9 +900,9 @@ __global__ __launch_bounds__(kBlock) void k_gather(DevState st, CorrectArgs a, P
         else if (kPredict) st.small[12 + (tid - 24)] = ps.Q[tid - 24];
     }
 #ifdef EKF_GATHER_STAMPS
-    EKF_STAMP();                                                  // 6: outputs issued
+    EKF_STAMP();                                                  // 4: outputs issued
     __syncthreads();
-    if (c == 0) for (int i = 0; i < 9; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
+    if (c == 0) for (int i = 0; i < 7; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
 #endif
 #undef EKF_STAMP
 }
@@ -1207,12 +1343,12 @@ hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, h
 hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
                          hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
-    const int64_t grid = cdiv(cols, kBlock);
+    const int64_t grid = cdiv(cols, kGatherCols);
     PanelView pv;
     pv.recv = nullptr; pv.slab = 0; pv.offset = 0; pv.Ij = 0; pv.patched = 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
-#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
     if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
     else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
 #undef EKF_G
@@ -1257,12 +1393,12 @@ hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, i
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
                                  int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
-    const int64_t grid = cdiv(cols, kBlock);
+    const int64_t grid = cdiv(cols, kGatherCols);
     PanelView pv;
     pv.recv = recv; pv.slab = rank_stride; pv.offset = offset; pv.Ij = a.j >> st.tm.shift; pv.patched = patched ? 1 : 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
-#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, pv, pa)
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
     if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
     else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
 #undef EKF_G
@@ -1419,11 +1555,8 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
                 tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
             }
         };
-#ifndef EKF_FLUSH_ABLATE
-#define EKF_FLUSH_ABLATE 0          // probes only (scripts/ab_flush.sh): 1 = no MFMA loop, 3 = no operand staging either (tile stream alone)
-#endif
         fetch(0, npairs < kChunk ? npairs : kChunk);
-        for (int c0 = 0; c0 < ((EKF_FLUSH_ABLATE & 2) ? 0 : npairs); c0 += kChunk) {
+        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
             const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
             __syncthreads();                                          // everyone is done with the previous chunk
 #pragma unroll
@@ -1440,7 +1573,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
             }
             __syncthreads();
             if (c0 + kChunk < npairs) fetch(c0 + kChunk, npairs - c0 - kChunk < kChunk ? npairs - c0 - kChunk : kChunk);
-            const int ksteps = (EKF_FLUSH_ABLATE & 1) ? (Gs[0][tid & 127] == 1.2345e300 ? 1 : 0) : (cn + 1) >> 1;   // two pairs = four rank-1 terms per MFMA
+            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
 #pragma unroll 2
             for (int ks = 0; ks < ksteps; ++ks) {
                 const double a = Ks[4 * ks + lr][wave * 16 + lc];
@@ -1458,195 +1591,6 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
                         acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
                     }
             }
-        }
-#pragma unroll
-        for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int e = 0; e < kE; ++e)
-                    __builtin_nontemporal_store((TS)acc[bp][e][r], td + (int64_t)(4 * r) * T + 16 * kE * bp + e);
-    }
-}
-
-// Batched flush, pipelined form (round 2) -- same arithmetic, same bits as k_flush_mfma; what changes is WHO waits for WHAT.
-// In k_flush_mfma the four wavefronts of a workgroup load their tile slab, then run the chunk loop (stage operands -> barrier ->
-// MFMA), then store: while they are in the matrix phase they have no tile traffic in flight, and a tile prefetch in registers
-// was blocked by the operand fetches of the later chunks queuing BEHIND it (vector-memory results return in order per
-// wavefront).  Measured (profiles/round2_tuning.md): tile stream alone 0.55 ms, matrix work alone 0.36 ms, together 0.61 ms.
-// Here the two kinds of traffic are issued by different wavefronts:
-//   * wavefront 4 (the STAGER) streams the pending (K, G) operands of every chunk global -> registers -> LDS, one chunk ahead of
-//     the matrix wavefronts, into a double-buffered operand image;
-//   * wavefronts 0-3 (MATRIX) own 16 rows x 128 columns each; their vector-memory queue carries only tile loads and stores, so
-//     the NEXT work item's slab is requested before the current item's MFMA loop and lands behind it.
-// A workgroup is persistent: it walks every nwg-th item of its XCD's stream.  One raw s_barrier per chunk (LDS visibility by
-// lgkmcnt(0) on the writer's side); no __syncthreads(), whose fence would drain the prefetch.
-struct FlushItem { int2 ij; int slab, cpart; };
-
-template <typename TS, int T, int kChunk, int kStagers>
-__global__ __launch_bounds__(256 + 64 * kStagers)
-void k_flush_pipe(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
-                  const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
-                  int npairs, TileMap tm) {
-    constexpr int kRows = 64, kCols = 128, kKPad = kRows + 16;
-    constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
-    constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
-    constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
-    static_assert(kBP * kE == 8 && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 columns = 8 MFMA blocks");
-    static_assert(kChunk % 2 == 0, "whole MFMA k-steps");
-    __shared__ __attribute__((aligned(16))) double Gs[2][2 * kChunk][kCols];
-    __shared__ double Ks[2][2 * kChunk][kKPad];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xs = blockIdx.x & 7;                                    // stream == XCD (round-robin dispatch: a speed assumption only)
-    const int lb = blockIdx.x >> 3, nwg = gridDim.x >> 3;             // position among the workgroups walking this stream
-    const int2 *__restrict__ wk = work + (int64_t)xs * nwork;
-    // valid tiles of this stream (padding (-1,-1) only at its end): uniform binary search
-    int lo = 0, hi = (int)nwork;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (wk[mid].x >= 0) lo = mid + 1; else hi = mid; }
-    const int nvalid = lo * kSubsPerTile;
-    const int nitems = lb < nvalid ? (nvalid - lb + nwg - 1) / nwg : 0;
-    const int nchunks = (npairs + kChunk - 1) / kChunk;
-    auto item_at = [&](int k) {
-        const int vi = lb + k * nwg;
-        const int w = vi / kSubsPerTile, sub = vi - w * kSubsPerTile;
-        FlushItem it;
-        it.ij = wk[w];
-        it.slab = sub / kColParts; it.cpart = sub - it.slab * kColParts;
-        return it;
-    };
-#ifndef EKF_PIPE_ABLATE
-#define EKF_PIPE_ABLATE 0           // probes only: 1 = no MFMA, 2 = stager idle, 4 = no barriers
-#endif
-    auto chunk_barrier = [] { if (!(EKF_PIPE_ABLATE & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    if (nitems == 0) return;                                          // uniform per workgroup: no barrier is left unmatched
-
-    if (wave >= 4) {
-        // ------------------------------------------------ STAGER ------------------------------------------------
-        // kStagers wavefronts take the chunks round-robin (stager t: chunks q = t mod kStagers): a chunk's operands are requested
-        // kStagers chunk periods before they are written to LDS -- one period does not cover an L2 round trip under full HBM
-        // load (measured: 0.96 ms per pass with one stager, the matrix wavefronts waiting at every chunk barrier)
-        const int me = wave - 4;
-        constexpr int kPerG = kChunk * kCols / 64, kPerK = kChunk * kRows / 64;     // double2 per lane and chunk
-        static_assert(kCols == 128 && kRows == 64, "the stager's index arithmetic below is written for 128 columns x 64 rows");
-        // Everything but the lane offset is wave-uniform and most of it compile-time: register j of a lane holds pair (j >> 1),
-        // column lane + 64 (j & 1) of G, and pair j, row lane of K.  One wavefront must stage a chunk in less than the matrix
-        // wavefronts' 2048 MFMA cycles on it -- with per-element index arithmetic and predicated writes it took ~2.4 us, and the
-        // whole pass ran at the stager's pace (0.96 ms).
-        double2 rg[kPerG], rk[kPerK];
-        const int64_t ps2 = pair_stride >> 1;                         // slot stride in double2
-        auto load_chunk = [&](int q) {
-            const int k = q / nchunks, c0 = (q - k * nchunks) * kChunk;
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            const FlushItem it = item_at(k);
-            const double2 *__restrict__ gb = reinterpret_cast<const double2 *>(Gp) + ((int64_t)it.ij.y * T + it.cpart * kCols) + lane;
-            const double2 *__restrict__ kb = reinterpret_cast<const double2 *>(Kp) + ((int64_t)it.ij.x * T + it.slab * kRows) + lane;
-#pragma unroll
-            for (int i = 0; i < kChunk; ++i) {
-                const int ii = i < cn ? i : cn - 1;                   // clamp: always a valid pair, written only if in range
-                const int64_t so = (int64_t)ring_slot(pstart, c0 + ii, pcap) * ps2;      // scalar
-                rg[2 * i] = gb[so]; rg[2 * i + 1] = gb[so + 64];
-                rk[i] = kb[so];
-            }
-        };
-        auto write_chunk = [&](int q) {
-            const int k = q / nchunks, c0 = (q - k * nchunks) * kChunk;
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            double *__restrict__ gd = &Gs[q & 1][0][lane];
-            double *__restrict__ kd = &Ks[q & 1][0][lane];
-            if (cn == kChunk) {                                       // a full chunk: straight-line stores at immediate offsets
-#pragma unroll
-                for (int i = 0; i < kChunk; ++i) {
-                    gd[(2 * i) * kCols] = rg[2 * i].x;          gd[(2 * i + 1) * kCols] = rg[2 * i].y;
-                    gd[(2 * i) * kCols + 64] = rg[2 * i + 1].x; gd[(2 * i + 1) * kCols + 64] = rg[2 * i + 1].y;
-                    kd[(2 * i) * kKPad] = -rk[i].x;             kd[(2 * i + 1) * kKPad] = -rk[i].y;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < kChunk; ++i) {
-                    if (i < cn) {
-                        gd[(2 * i) * kCols] = rg[2 * i].x;          gd[(2 * i + 1) * kCols] = rg[2 * i].y;
-                        gd[(2 * i) * kCols + 64] = rg[2 * i + 1].x; gd[(2 * i + 1) * kCols + 64] = rg[2 * i + 1].y;
-                        kd[(2 * i) * kKPad] = -rk[i].x;             kd[(2 * i + 1) * kKPad] = -rk[i].y;
-                    } else if (i == cn) {                             // pad of an odd count: A = -0.0, B = +0.0
-                        gd[(2 * i) * kCols] = 0.0;      gd[(2 * i + 1) * kCols] = 0.0;
-                        gd[(2 * i) * kCols + 64] = 0.0; gd[(2 * i + 1) * kCols + 64] = 0.0;
-                        kd[(2 * i) * kKPad] = -0.0;     kd[(2 * i + 1) * kKPad] = -0.0;
-                    }
-                }
-            }
-        };
-        const int Q = nitems * nchunks;
-        // my chunks: me, me + kStagers, ...; `mine` = the next one I have to write, its operands already requested
-        int mine = me;
-        if (mine < Q) load_chunk(mine);
-        if (me == 0) { write_chunk(0); mine += kStagers; if (mine < Q) load_chunk(mine); }
-        chunk_barrier();                                              // #0: chunk 0 visible
-        for (int q = 0; q < Q; ++q) {
-            // the matrix wavefronts are on chunk q (buffer q & 1); buffer (q + 1) & 1 was released by barrier #q
-            if (q + 1 == mine && !(EKF_PIPE_ABLATE & 2)) {
-                write_chunk(mine);
-                mine += kStagers;
-                if (mine < Q) load_chunk(mine);
-            }
-            chunk_barrier();                                          // #(q+1): chunk q + 1 visible, buffer q & 1 free
-        }
-        return;
-    }
-
-    // ---------------------------------------------------- MATRIX ----------------------------------------------------
-    const int lr = lane >> 4, lc = lane & 15;                         // MFMA k / row-group index, MFMA row / column index
-    auto slab_offset = [&](const FlushItem &it) {
-        return tm.tile_offset(it.ij.x, it.ij.y) + (int64_t)(it.slab * kRows + wave * 16 + lr) * T + it.cpart * kCols + kE * lc;
-    };
-    TS nxt[kBP][4][kE];                                               // the NEXT item's slab, in flight behind this item's MFMA loop
-    auto request = [&](int k) {
-        const TS *__restrict__ tp = tiles + slab_offset(item_at(k));
-#pragma unroll
-        for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int e = 0; e < kE; ++e)                          // adjacent scalars: one 16-byte nontemporal load
-                    nxt[bp][r][e] = __builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 16 * kE * bp + e);
-    };
-    request(0);
-    chunk_barrier();                                                  // #0
-    int q = 0;
-    for (int k = 0; k < nitems; ++k) {
-        d4_t acc[kBP][kE];                                            // [16-byte group bp][column e in it][row r -> +4r]
-#pragma unroll
-        for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int e = 0; e < kE; ++e) acc[bp][e][r] = (double)nxt[bp][r][e];
-        TS *__restrict__ td = dst + slab_offset(item_at(k));
-        if (k + 1 < nitems) request(k + 1);
-        for (int c = 0; c < nchunks; ++c, ++q) {
-            const int c0 = c * kChunk;
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            const int b = q & 1;
-            const int ksteps = (EKF_PIPE_ABLATE & 1) ? (Gs[0][0][lane] == 1.2345e300 ? 1 : 0) : (cn + 1) >> 1;   // two pairs = four rank-1 terms per MFMA
-#pragma unroll 2
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const double a = Ks[b][4 * ks + lr][wave * 16 + lc];
-                double2 bv[kBP][kE / 2];
-#pragma unroll
-                for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-                    for (int h = 0; h < kE / 2; ++h)
-                        bv[bp][h] = *reinterpret_cast<const double2 *>(&Gs[b][4 * ks + lr][16 * kE * bp + kE * lc + 2 * h]);
-#pragma unroll
-                for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-                    for (int h = 0; h < kE / 2; ++h) {
-                        acc[bp][2 * h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].x, acc[bp][2 * h], 0, 0, 0);
-                        acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
-                    }
-            }
-            chunk_barrier();                                          // #(q+1): done reading buffer b; chunk q + 1 visible
         }
 #pragma unroll
         for (int bp = 0; bp < kBP; ++bp)
@@ -1678,27 +1622,6 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;
         if (!use_mfma || npairs < kMinPairs || !work_xcd || xcd_len <= 0) return false;
         constexpr int kSubs = (T / 64) * (T / 128);
-        // pipelined form (k_flush_pipe): persistent workgroups, stager + matrix wavefronts; EKF_FLUSH_PIPE=0 -> round 1's kernel,
-        // EKF_FLUSH_PIPE_WGS = workgroups per CU (default 2 = what its registers and LDS allow)
-        static const int use_pipe = [] { const char *v = getenv("EKF_FLUSH_PIPE"); return v ? atoi(v) : 1; }();
-        static const int pipe_min = [] { const char *v = getenv("EKF_FLUSH_PIPE_MIN"); return v ? atoi(v) : 2; }();
-        if (use_pipe && npairs >= pipe_min) {
-            static const int wgs_per_cu = [] { const char *v = getenv("EKF_FLUSH_PIPE_WGS"); const int x = v ? atoi(v) : 2; return x < 1 ? 1 : x; }();
-            int ncu = 256;
-            { int dev = 0; hipDeviceProp_t prop; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount; }
-            int64_t grid = (int64_t)ncu * wgs_per_cu;
-            grid -= grid % 8;                                          // whole sets of 8: workgroup b walks stream b % 8
-            if (grid < 8) grid = 8;
-            const int64_t most = 8 * xcd_len * kSubs;
-            if (grid > most) grid = most - most % 8 > 0 ? most - most % 8 : 8;
-            static const int stagers = [] { const char *v = getenv("EKF_FLUSH_PIPE_STAGERS"); return v ? atoi(v) : 2; }();
-#define EKF_PIPE(NS) hipLaunchKernelGGL((k_flush_pipe<TS, T, 8, NS>), dim3((unsigned)grid), dim3(256 + 64 * NS), 0, s, (const TS *)st.tiles, \
-                                        (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm)
-            if (stagers <= 1) EKF_PIPE(1); else if (stagers == 2) EKF_PIPE(2); else if (stagers == 3) EKF_PIPE(3); else EKF_PIPE(4);
-#undef EKF_PIPE
-            name_kernel(kname, "k_flush_pipe", sizeof(TS), T, 8, -1);
-            return true;
-        }
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if (npairs <= chunk_switch)
