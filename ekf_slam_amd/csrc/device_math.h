@@ -16,15 +16,22 @@ namespace ekfm {
 constexpr double kD2R = 0.017453292519943295;
 constexpr double kR2D = 57.29577951308232;
 
-// a (deg) = 90*n + r with r in [-45,45]; quad = n mod 4.  round() is half-away-from-zero.
+// a (deg) = 90*n + r with r in [-45,45]; quad = n mod 4; n = round(a / 90), halves away from zero.
 // No fmod: for |a| < 2^40 the quotient of an exact multiple of 90 is exact, 90*n is exactly representable and
 // a - 90*n is exact (Sterbenz), so r (and exactness at multiples of 90 degrees) is the same as reducing
 // mod 360 first -- and f64 fmod is by far the slowest thing in these kernels' scalar prologues.
+// No division either (an f64 division is a ~15-instruction dependent sequence, and this runs twice in the latency chain of every
+// update-step): n is first taken from a * (1/90), which is within one ulp of a / 90 and can therefore only be off by one
+// where a / 90 is within an ulp of k + 1/2, i.e. where |r| comes out at or just beyond 45; r = a - 90 n is exact for either
+// candidate, so ONE correction step restores exactly the n that round(a / 90) gives, ties (|r| == 45) included.
 EKF_MHD void reduce90(double a, double &r, int &quad) {
     if (fabs(a) >= 1099511627776.0) a = fmod(a, 360.0);
-    const double q = a / 90.0;
-    const double n = copysign(floor(fabs(q) + 0.5), q);
+    const double q = a * (1.0 / 90.0);
+    double n = copysign(floor(fabs(q) + 0.5), q);
     r = fma(-90.0, n, a);
+    // round-half-away-from-zero of the TRUE quotient: r must lie in [-45, 45], and a tie goes to the larger |n|
+    if (r > 45.0 || (r == 45.0 && a > 0.0)) { n += 1.0; r -= 90.0; }
+    else if (r < -45.0 || (r == -45.0 && a < 0.0)) { n -= 1.0; r += 90.0; }
     quad = (int)(((long long)n) & 3);
 }
 

@@ -120,15 +120,15 @@ __device__ __forceinline__ void predict_common(double u0, double u1, double sn, 
     fb = u0 * cs;
     W[0] = u0 * cs; W[1] = u0 * sn; W[2] = u1;
 }
-// (F*P)(i,c) for the 3x3 robot block: rows 1, 2 pick up F(.,3) * P(3,c)
-__device__ __forceinline__ double predict_fp(const double *prr, int i, int c, double fa, double fb) {
-    return i == 0 ? prr[c] + fa * prr[6 + c] : i == 1 ? prr[3 + c] + fb * prr[6 + c] : prr[6 + c];
+// (F*P)(i,c) for the 3x3 robot block from column c of P = (x0, x1, x2): rows 1, 2 pick up F(.,3) * P(3,c).  Operands by VALUE so
+// that a lane-parallel caller hands over values it selected, with no indexed access to a register array (scratch) or to LDS.
+__device__ __forceinline__ double predict_fp(int i, double x0, double x1, double x2, double fa, double fb) {
+    return i == 0 ? x0 + fa * x2 : i == 1 ? x1 + fb * x2 : x2;
 }
-// entry (i,j) of F*Prr*F' + Q and of Q = (W*C)*W'  (EKF_SLAM.m:44,47)
-// (wi, wj = W(i), W(j): passed by value so that a lane-parallel caller selects them instead of indexing a register array)
-__device__ __forceinline__ void predict_prr_entry(const double *prr, int i, int j, double fa, double fb, double wi, double wj, double C,
-                                                  double &out, double &q) {
-    const double m1 = predict_fp(prr, i, j, fa, fb), p2 = predict_fp(prr, i, 2, fa, fb);
+// entry (i,j) of F*Prr*F' + Q and of Q = (W*C)*W'  (EKF_SLAM.m:44,47); cj / c2 = columns j and 3 of Prr, wi / wj = W(i), W(j)
+__device__ __forceinline__ void predict_prr_entry(int i, int j, const double cj[3], const double c2[3], double fa, double fb, double wi,
+                                                  double wj, double C, double &out, double &q) {
+    const double m1 = predict_fp(i, cj[0], cj[1], cj[2], fa, fb), p2 = predict_fp(i, c2[0], c2[1], c2[2], fa, fb);
     const double m2 = j == 0 ? m1 + fa * p2 : j == 1 ? m1 + fb * p2 : m1;                   // (F*P)*F'
     q = (wi * C) * wj;
     out = m2 + q;
@@ -146,7 +146,10 @@ __device__ __forceinline__ void predict_finish(const double pose[3], const doubl
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) predict_prr_entry(prr_in, i, j, o.fa, o.fb, W[i], W[j], C, o.prr[3 * i + j], o.Q[3 * i + j]);
+        for (int j = 0; j < 3; ++j) {
+            const double cj[3] = { prr_in[j], prr_in[3 + j], prr_in[6 + j] }, c2[3] = { prr_in[2], prr_in[5], prr_in[8] };
+            predict_prr_entry(i, j, cj, c2, o.fa, o.fb, W[i], W[j], C, o.prr[3 * i + j], o.Q[3 * i + j]);
+        }
 #pragma unroll
     for (int i = 0; i < 3; ++i) o.pose[i] = predict_pose_entry(pose, i, u0, u1, sn2, cs2);
 }
@@ -511,10 +514,10 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
     __shared__ PredictSmall ps;
-    __shared__ double gs_sh[10], phi_sh[4];
     __shared__ double pose_sh[3];                   // the pose the correction starts from (predicted when predict is folded in);
                                                     // pss[19..21] keep the BASE pose: the BEARING wavefront reads it concurrently
-    __shared__ int diag_ready;
+    __shared__ int diag_ready;                      // DIAG -> CHAIN: the patched 2x2 block is in pss[15..18]
+    __shared__ int staged_cnt;                      // column wavefronts that have written their share of `upatch` (0..4)
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3 columns, 4 chain, 5 diag, 6 bearing
@@ -552,37 +555,49 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
 
     if (role >= 4) {
         // =========================================== helper wavefronts ===========================================
-        // (1h) the 5x5 sub-block P(S,S), the pose, the landmark: 24 doubles, one per lane of the CHAIN wavefront (unconditional
-        //      selected addresses, see the column path)
+        // (1h) the small operands, one per lane: the CHAIN wavefront takes what the previous kernel wrote a moment ago (robot block,
+        //      strip columns j, j+1, pose, landmark: 20 doubles, cache-resident), the DIAG wavefront the landmark's own 2x2 block,
+        //      which comes from the tile store in HBM -- two wavefronts, two load queues, so the chain's sincos starts when the
+        //      POSE has arrived, not when the slowest of 24 loads has (vector-memory results return in order per wavefront).
+        //      Unconditional selected addresses, see the column path.
+        // Synchronisation: ONE early hardware barrier ("0", right after everyone has REQUESTED its loads, so that the two LDS flags
+        // below are known to be reset) and one at the end ("B").  In between the wavefronts meet through LDS flags only, each waiting
+        // for exactly what it needs: CHAIN and BEARING for their own loads, DIAG for the column wavefronts' staging of `upatch`.
+        double small_v = 0.0;
         if (role == 4) {
-            const double *sp = prr_cur;                                  // lanes >= 24 re-read Prr(1,1), unused
+            const double *sp = prr_cur;                                  // idle lanes re-read Prr(1,1), unused
             if (lane < 9) sp = prr_cur + lane;
             else if (lane < 15) { const int t = (lane - 9) >> 1, b = (lane - 9) & 1; sp = strip + t * ldm + j + b; }
             else if (lane >= 19 && lane < 22) sp = x + (lane - 19);
             else if (lane >= 22 && lane < 24) sp = x + 3 + j + (lane - 22);
-            double small_v = *sp;
-            if (lane >= 15 && lane < 19) {
-                const int t = (lane - 15) >> 1, b = (lane - 15) & 1;     // canonical P(j+t, j+b)
-                if (kSharded) {
-                    const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
-                    small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
-                } else {
-                    // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
-                    const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
-                    const int rr = t > b ? t : b, cc2 = t > b ? b : t;
-                    small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
-                }
+            small_v = *sp;
+            if (lane == 24) { diag_ready = 0; staged_cnt = 0; }
+        } else if (role == 5) {
+            const int t = (lane >> 1) & 1, b = lane & 1;                 // lanes 0..3: canonical P(j+t, j+b)
+            if (kSharded) {
+                const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
+                small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
+            } else {
+                // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
+                const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
+                const int rr = t > b ? t : b, cc2 = t > b ? b : t;
+                small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
             }
-            if (lane < 24) pss[lane] = small_v;
-            if (lane == 24) diag_ready = 0;
+        } else {
+            small_v = x[lane < 3 ? lane : 3 + j + ((lane - 3) & 1)];       // BEARING: lanes 0..2 the pose, 3..4 the landmark
         }
-        EKF_STAMP();                                                  // 1: small operands requested / staged
-        __syncthreads();                                              // barrier A: pss (base values) and upatch staged
-        EKF_STAMP();                                                  // 2
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");                       // barrier 0: no waitcnt -- the loads stay in flight across it
+        EKF_STAMP();                                                  // 1
+        if (role == 4 && (lane < 15 || (lane >= 19 && lane < 24))) pss[lane] = small_v;      // (the column lanes read these after B)
+        if (role == 5 && lane < 4) pss[15 + lane] = small_v;
+        EKF_STAMP();                                                  // 2: own operands arrived
         if (role == 5) {
             // ---- DIAG: canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so
             //      that the LDS latency is paid per group, not per pair
             if (do_patch && npend > 0) {
+                while (*(volatile int *)&staged_cnt < 4) { }          // the four column wavefronts have staged `upatch`
+                wave_lds_sync();
                 if (lane < 3) {
                     const int q = lane;
                     const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
@@ -599,14 +614,16 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
                     }
                     if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
                 }
-                wave_lds_sync();                                          // the patched block is written ...
-                if (lane == 0) *(volatile int *)&diag_ready = 1;          // ... before the flag (one wavefront: LDS order = program order)
             }
+            wave_lds_sync();                                              // the (patched) block is written ...
+            if (lane == 0) *(volatile int *)&diag_ready = 1;              // ... before the flag (one wavefront: LDS order = program order)
         } else if (role == 6) {
             // ---- BEARING: nu = z - z_k, z_k = [sqrt(q); wrapTo360(atan2d(dy,dx) - heading)]  (EKF_SLAM.m:125-130,144), from the
             //      PREDICTED pose when predict is folded in -- same expressions as the chain wavefront's, so the same bits
+            const double bx = lane_bcast(small_v, 0), by = lane_bcast(small_v, 1), bth = lane_bcast(small_v, 2),
+                         blx = lane_bcast(small_v, 3), bly = lane_bcast(small_v, 4);
             if (lane == 0) {
-                double pose[3] = { pss[19], pss[20], pss[21] };
+                double pose[3] = { bx, by, bth };
                 if (kPredict) {
                     const double2 sc2 = sincosd_ni(pose[2] + pa.u1);
                     const double sn2 = sc2.x, cs2 = sc2.y;
@@ -614,80 +631,81 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
                                  p2 = predict_pose_entry(pose, 2, pa.u0, pa.u1, sn2, cs2);
                     pose[0] = p0; pose[1] = p1; pose[2] = p2;
                 }
-                const double d0 = pss[22] - pose[0], d1 = pss[23] - pose[1];
+                const double d0 = blx - pose[0], d1 = bly - pose[1];
                 const double bearing = bearing_ni(d1, d0, pose[2]);
                 const double sq = sqrt(d0 * d0 + d1 * d1);
                 sol.nu[0] = a.z0 - sq;                                    // :144 (bearing NOT wrapped)
                 sol.nu[1] = a.z1 - bearing;
             }
         } else {
-            // ---- CHAIN: each matrix entry of the solve is formed on its own lane.  Operands whose index depends on the lane are read
-            //      from the LDS copy `pss` (a register array indexed by the lane would live in scratch memory); what every lane
-            //      needs identically (pose, landmark, H_s, inv(phi)) is computed redundantly in registers.
+            // ---- CHAIN: each matrix entry of the solve is formed on its own lane.  Every lane holds the 24 small operands in
+            //      registers (static indices only: an array indexed by the lane would live in scratch memory) and SELECTS the ones
+            //      its entry needs; what every lane needs identically (pose, H_s, inv(phi)) is computed redundantly; entries travel
+            //      between lanes by v_readlane (G(:,S), phi) or, where each lane needs a different subset, through `pss` in LDS.
+            wave_lds_sync();                                          // own LDS writes above (one wavefront: in order)
+            double p[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) p[i] = (i >= 15 && i < 19) ? 0.0 : pss[i];      // 15..18 belong to DIAG: read later, from LDS
             double fa = 0.0, fb = 0.0;
-            double pose[3] = { pss[19], pss[20], pss[21] };
-            const double lmx = pss[22], lmy = pss[23];
+            double pose[3] = { p[19], p[20], p[21] };
             if (kPredict) {
                 // predict(u) folded into this correction: same per-entry arithmetic as k_predict (predict_*_entry)
                 const double2 sc_l = sincosd_ni((lane & 1) ? pose[2] + pa.u1 : pose[2]);   // lane 0: pre-motion heading, lane 1: + u2
+                EKF_STAMP();                                          // (probe) sincos
                 const double sn = lane_bcast(sc_l.x, 0), cs = lane_bcast(sc_l.y, 0), sn2 = lane_bcast(sc_l.x, 1), cs2 = lane_bcast(sc_l.y, 1);
                 double W[3];
                 predict_common(pa.u0, pa.u1, sn, cs, fa, fb, W);
-                double mine = 0.0, myq = 0.0;                         // lane l: l < 9 Prr'(l/3, l%3) and Q; 9..14 strip'(t, j+b)
-                if (lane < 9) {
-                    const int ei = lane / 3, ej = lane - 3 * ei;
-                    const double wi = ei == 0 ? W[0] : ei == 1 ? W[1] : W[2], wj = ej == 0 ? W[0] : ej == 1 ? W[1] : W[2];
-                    predict_prr_entry(pss, ei, ej, fa, fb, wi, wj, pa.C, mine, myq);
-                }
-                else if (lane < 15) {
-                    const int t = (lane - 9) >> 1, b = (lane - 9) & 1;
-                    double s0 = pss[9 + b], s1 = pss[11 + b];
-                    const double s2 = pss[13 + b];
-                    predict_strip(s0, s1, s2, fa, fb);
-                    mine = t == 0 ? s0 : t == 1 ? s1 : s2;
-                }
+                // lane l < 9: Prr'(l/3, l%3) and Q; 9..14: strip'(t, j+b), t = (l-9)>>1, b = (l-9)&1.  All lanes run both forms and
+                // keep theirs (no divergent branches: the two forms are a dozen operations each)
+                const int ei = lane >= 6 ? 2 : lane >= 3 ? 1 : 0, ej = lane - 3 * ei;
+                double cj[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cj[k] = ej == 0 ? p[3 * k] : ej == 1 ? p[3 * k + 1] : p[3 * k + 2];
+                const double c2[3] = { p[2], p[5], p[8] };
+                const double wi = ei == 0 ? W[0] : ei == 1 ? W[1] : W[2], wj = ej == 0 ? W[0] : ej == 1 ? W[1] : W[2];
+                double e_prr, e_q;
+                predict_prr_entry(ei, ej, cj, c2, fa, fb, wi, wj, pa.C, e_prr, e_q);
+                const int st_t = (lane - 9) >> 1, st_b = (lane - 9) & 1;
+                double s0 = st_b ? p[10] : p[9], s1 = st_b ? p[12] : p[11];
+                const double s2 = st_b ? p[14] : p[13];
+                predict_strip(s0, s1, s2, fa, fb);
+                const double e_strip = st_t == 0 ? s0 : st_t == 1 ? s1 : s2;
                 const double p0 = predict_pose_entry(pose, 0, pa.u0, pa.u1, sn2, cs2), p1 = predict_pose_entry(pose, 1, pa.u0, pa.u1, sn2, cs2),
                              p2 = predict_pose_entry(pose, 2, pa.u0, pa.u1, sn2, cs2);      // every lane (3 operations)
                 pose[0] = p0; pose[1] = p1; pose[2] = p2;
-                wave_lds_sync();                                      // every lane has READ its operands ...
-                if (lane < 15) pss[lane] = mine;                      // ... before anyone overwrites them; the column lanes read Prr'
-                if (lane < 9) ps.Q[lane] = myq;                       // and strip' from here
+                EKF_STAMP();                                          // (probe) entries formed
+                if (lane < 15) pss[lane] = lane < 9 ? e_prr : e_strip;    // the column lanes and the G(:,S) lanes read Prr', strip' from here
+                if (lane < 9) ps.Q[lane] = e_q;
                 if (lane == 0) { ps.fa = fa; ps.fb = fb; }
-                wave_lds_sync();
             }
             if (lane < 3) pose_sh[lane] = lane == 0 ? pose[0] : lane == 1 ? pose[1] : pose[2];
-            EKF_STAMP();                                              // 3: predict entries exchanged
             SmallSolve so;
             double sq;
-            solve_hs(lmx - pose[0], lmy - pose[1], sq, so.Hs);        // EKF_SLAM.m:125-127,137-138 (every lane, redundantly)
-            if (do_patch && npend > 0) {
-                while (*(volatile int *)&diag_ready == 0) { }         // the DIAG wavefront's patched 2x2 block is in pss[15..18]
-                wave_lds_sync();
-            }
+            solve_hs(p[22] - pose[0], p[23] - pose[1], sq, so.Hs);    // EKF_SLAM.m:125-127,137-138 (every lane, redundantly)
+            EKF_STAMP();                                              // 3: H_s
+            while (*(volatile int *)&diag_ready == 0) { }             // the DIAG wavefront's (patched) 2x2 block is in pss[15..18]
+            wave_lds_sync();                                          // pss: predicted entries (own writes) and that block
             const int ra = lane >= 5 ? 1 : 0;                         // row of this lane's G(:,S) entry
             double hsel[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) hsel[t] = ra ? so.Hs[1][t] : so.Hs[0][t];
-            if (lane < 10) gs_sh[lane] = solve_gs_entry(pss, hsel, lane - 5 * ra);
-            wave_lds_sync();
+            const double e_gs = solve_gs_entry(pss, hsel, lane < 10 ? lane - 5 * ra : 0);
             double GS[2][5];
 #pragma unroll
-            for (int i = 0; i < 10; ++i) GS[i / 5][i % 5] = gs_sh[i];
+            for (int i = 0; i < 10; ++i) GS[i / 5][i % 5] = lane_bcast(e_gs, i);
+            double e_phi;
             {
                 const int aa = (lane >> 1) & 1, bb = lane & 1;
                 double gsel[5], hb[5];
 #pragma unroll
                 for (int t = 0; t < 5; ++t) { gsel[t] = aa ? GS[1][t] : GS[0][t]; hb[t] = bb ? so.Hs[1][t] : so.Hs[0][t]; }
                 const double Rab = aa == 0 ? (bb == 0 ? a.R00 : a.R01) : (bb == 0 ? a.R10 : a.R11);
-                if (lane < 4) phi_sh[lane] = solve_phi_entry(gsel, hb, Rab);                // :141
+                e_phi = solve_phi_entry(gsel, hb, Rab);                                      // :141
             }
-            wave_lds_sync();
-            double phi[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) phi[i] = phi_sh[i];
+            const double phi[4] = { lane_bcast(e_phi, 0), lane_bcast(e_phi, 1), lane_bcast(e_phi, 2), lane_bcast(e_phi, 3) };
             ekfm::inv2(phi, so.Phi);                                  // :143 phi_k^-1 (every lane, redundantly)
             EKF_STAMP();                                              // 4: solve
-            // publish: H_s and inv(phi) from lane 0 (static indices), K_r and G_r one entry per lane (operands by LDS index)
+            // publish: H_s and inv(phi) from lane 0 (static indices), K_r and G_r one entry per lane (operands selected)
             if (lane == 0) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) sol.Hs[i / 5][i % 5] = so.Hs[i / 5][i % 5];
@@ -695,16 +713,39 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
                 for (int i = 0; i < 4; ++i) sol.Phi[i] = so.Phi[i];
             } else if (lane >= 14 && lane < 20) {
                 const int b = (lane - 14) >> 1, cc = (lane - 14) & 1;
-                sol.Kr[b][cc] = solve_kr_entry(gs_sh[b], gs_sh[5 + b], cc ? so.Phi[1] : so.Phi[0], cc ? so.Phi[3] : so.Phi[2]);
+                const double g0b = b == 0 ? GS[0][0] : b == 1 ? GS[0][1] : GS[0][2], g1b = b == 0 ? GS[1][0] : b == 1 ? GS[1][1] : GS[1][2];
+                sol.Kr[b][cc] = solve_kr_entry(g0b, g1b, cc ? so.Phi[1] : so.Phi[0], cc ? so.Phi[3] : so.Phi[2]);
             } else if (lane >= 20 && lane < 26) {
                 const int aa = (lane - 20) >= 3 ? 1 : 0, b = (lane - 20) - 3 * aa;
-                sol.Gr[aa][b] = gs_sh[5 * aa + b];
+                const double g0b = b == 0 ? GS[0][0] : b == 1 ? GS[0][1] : GS[0][2], g1b = b == 0 ? GS[1][0] : b == 1 ? GS[1][1] : GS[1][2];
+                sol.Gr[aa][b] = aa ? g1b : g0b;
             }
         }
         __syncthreads();                                              // barrier B: sol, ps, pss complete
+        if (blockIdx.x == 0) {
+            // the replicated small outputs of workgroup 0, beside the column lanes' outputs, not in front of them, one KIND per
+            // helper wavefront (run by one wavefront the five kinds are five divergent branches back to back, ~1 900 clocks at the
+            // tail of the kernel): x_r (x(3) NOT re-wrapped) | Prr | G_r, K_r, Q for the host-side getters
+            if (role == 4) {
+                if (lane < 3) x_nxt[lane] = pose_sh[lane] + (sol.Kr[lane][0] * sol.nu[0] + sol.Kr[lane][1] * sol.nu[1]);
+            } else if (role == 5) {
+                if (lane < 9) {
+                    const int r = lane / 3, b = lane - 3 * r;
+                    prr_nxt[3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
+                }
+            } else {
+                if (lane < 6) { const int r = lane / 3, b = lane - 3 * r; st.small[3 * r + b] = sol.Gr[r][b]; }
+                else if (lane < 12) { const int b = (lane - 6) >> 1, r = (lane - 6) & 1; st.small[6 + 2 * b + r] = sol.Kr[b][r]; }
+#if !defined(EKF_GATHER_STAMPS) || EKF_GATHER_STAMPS != 2                 // (that probe build returns the chain's stamps in the Q slots)
+                else if (kPredict && lane < 21) st.small[12 + (lane - 12)] = ps.Q[lane - 12];
+#endif
+            }
+        }
 #ifdef EKF_GATHER_STAMPS
-        EKF_STAMP();                                                  // 5
-        if (blockIdx.x == 0 && tid == kGatherCols) for (int i = 0; i < 6; ++i) st.small[21 + i] = (double)(stamp[i] - stamp[0]);
+        EKF_STAMP();                                                  // barrier B passed
+#if EKF_GATHER_STAMPS == 2                                                // the CHAIN wavefront's view (the Q slots hold one view per build)
+        if (blockIdx.x == 0 && tid == kGatherCols) for (int i = 0; i < 9; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
+#endif
 #endif
         return;
     }
@@ -743,9 +784,23 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         s0 = strip[c]; s1 = strip[ldm + c]; s2 = strip[2 * ldm + c];
         xc = x[3 + c];
     }
-    //     ... and this column's operands of the first kPre pending pairs (G_i(:,c) left of j, K_i(c,:) right of it), all in
-    //     flight together: they used to be fetched 8 at a time inside the patch loop, one L2 round trip per 8 pairs
-    //     (0.17 us per pending pair, scripts/probe_gather_phases.py).
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");                       // barrier 0 (see the helper path): flags reset, loads still in flight
+    EKF_STAMP();                                                  // b: all loads requested
+    // (2) stage the uniform operands (waits for the FIRST group of loads only); the four column wavefronts and DIAG meet on a
+    //     counter in LDS -- the CHAIN and BEARING wavefronts do not take part
+    upatch[tid] = up0; upatch[tid + kGatherCols] = up1;           // unconditional (entries past 4*npend are never read)
+    wave_lds_sync();
+    if ((tid & 63) == 0) atomicAdd(&staged_cnt, 1);
+    while (*(volatile int *)&staged_cnt < 4) { }
+    wave_lds_sync();
+    EKF_STAMP();                                                  // 1: uniform operands staged
+
+    // (2b) this column's operands of the first kPre pending pairs (G_i(:,c) left of j, K_i(c,:) right of it), all in flight
+    //     together (fetched 8 at a time inside the patch loop they cost one L2 round trip per 8 pairs).  Requested AFTER barrier
+    //     A: issuing these up to 32 loads takes the column wavefronts ~2 000 clocks, and before the barrier that was 2 000 clocks
+    //     the helper wavefronts -- the critical path -- spent waiting for them; behind it the column lanes have ~3 000 clocks of
+    //     slack until the solve is published (scripts/probe_gather_phases.py).
     // 32 pairs: a 64-pair variant (344 VGPRs, one workgroup per CU) was slower under an asynchronous flush (tuning log, sweep 12)
     constexpr int kPre = 32;
     const int npre = do_patch ? (npend < kPre ? npend : kPre) : 0;
@@ -783,11 +838,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         }
     }
 
-    EKF_STAMP();                                                  // b: all loads requested
-    // (2) stage the uniform operands (waits for the FIRST group of loads only)
-    upatch[tid] = up0; upatch[tid + kGatherCols] = up1;           // unconditional (entries past 4*npend are never read)
-    __syncthreads();                                              // barrier A
-    EKF_STAMP();                                                  // 1: uniform operands staged
 
     // (3) every lane applies the pending pairs to its own two row entries while the helper wavefronts run the solve
     if (live && do_patch) {
@@ -887,22 +937,12 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
     }
-    if (blockIdx.x == 0 && tid < 33) {
-        // the replicated small outputs, one entry per lane of workgroup 0 (they used to be ~35 dependent stores on one lane
-        // at the tail of the kernel): x_r (x(3) NOT re-wrapped), Prr, and G_r / K_r / Q for the host-side getters
-        if (tid < 3) x_nxt[tid] = pose_sh[tid] + (sol.Kr[tid][0] * sol.nu[0] + sol.Kr[tid][1] * sol.nu[1]);
-        else if (tid < 12) {
-            const int r = (tid - 3) / 3, b = (tid - 3) - 3 * r;
-            prr_nxt[3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
-        }
-        else if (tid < 18) { const int r = (tid - 12) / 3, b = (tid - 12) - 3 * r; st.small[3 * r + b] = sol.Gr[r][b]; }
-        else if (tid < 24) { const int b = (tid - 18) >> 1, r = (tid - 18) & 1; st.small[6 + 2 * b + r] = sol.Kr[b][r]; }
-        else if (kPredict) st.small[12 + (tid - 24)] = ps.Q[tid - 24];
-    }
 #ifdef EKF_GATHER_STAMPS
     EKF_STAMP();                                                  // 4: outputs issued
     __syncthreads();
+#if EKF_GATHER_STAMPS == 1                                                // column lane 0's view
     if (c == 0) for (int i = 0; i < 7; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
+#endif
 #endif
 #undef EKF_STAMP
 }

@@ -3,6 +3,7 @@
 #include "device_math.h"
 #include <cmath>
 #include <cstdio>
+#include <initializer_list>
 #include <random>
 static double ulp_err(double got, long double ref) {
     if (ref == 0) return got == 0 ? 0 : 1e9;
@@ -31,6 +32,29 @@ int main(int argc, char **argv) {
     // exactness at multiples of 90 degrees (cosd/sind call sites: EKF_SLAM.m:42,58-59)
     if (ekfm::sind(90) != 1 || ekfm::cosd(90) != 0 || ekfm::sind(180) != 0 || ekfm::cosd(180) != -1 || ekfm::sind(-270) != 1 ||
         ekfm::cosd(360) != 1 || ekfm::atan2d(1, 1) != 45 || ekfm::atan2d(1, 0) != 90 || ekfm::atan2d(0, -1) != 180) ++bad;
+    // reduce90 (division-free) must give exactly n = round-half-away-from-zero(a / 90) of the TRUE quotient (80-bit arithmetic
+    // here; the earlier floor(a / 90.0 + 0.5) form mis-rounded angles one ulp below 45 + 90 k to |r| > 45) and the exact
+    // remainder: random angles, every tie a = 90 k + 45 and its neighbours, multiples of 90, tiny and large magnitudes
+    auto ref_reduce = [](double a, double &r, int &quad) {
+        const long double n = roundl((long double)a / 90.0L);          // halves away from zero
+        r = (double)((long double)a - 90.0L * n);                       // exact: |a| < 2^40, 64-bit significand
+        quad = (int)(((long long)n) & 3);
+    };
+    auto same_reduce = [&](double a) {
+        double r1, r2; int q1, q2;
+        ekfm::reduce90(a, r1, q1); ref_reduce(a, r2, q2);
+        return r1 == r2 && q1 == q2 && fabs(r1) <= 45.0;
+    };
+    std::uniform_real_distribution<double> ang(-1.0e5, 1.0e5), small(-400, 400);
+    for (int i = 0; i < n; ++i) if (!same_reduce(ang(rng)) || !same_reduce(small(rng))) ++bad;
+    for (int k = -4000; k <= 4000; ++k)
+        for (double base : { 90.0 * k + 45.0, 90.0 * k, 90.0 * k - 45.0 }) {
+            double a = base;
+            for (int s = 0; s < 3; ++s) { if (!same_reduce(a)) ++bad; a = nextafter(a, INFINITY); }
+            a = base;
+            for (int s = 0; s < 3; ++s) { if (!same_reduce(a)) ++bad; a = nextafter(a, -INFINITY); }
+        }
+    for (double a : { 1e-300, -1e-300, 4.9e-324, 44.99999999999999, 45.00000000000001, 1e9 + 45.0, -1e9 - 45.0, 1.0e12 }) if (!same_reduce(a)) ++bad;
     printf("%.4f %.4f %.4f %.4f %d\n", ms, mc, ma, ma2, bad);
     return 0;
 }
