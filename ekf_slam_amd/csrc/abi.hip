@@ -102,6 +102,9 @@ struct ekf_handle {
     int2 *d_work_xcd = nullptr;
     int64_t xcd_len = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
+    AssocDecision *h_decision_dev = nullptr;   // device-side address of the mapped h_decision (the association kernel writes it)
+    int *d_ticket = nullptr;                   // k_associate's last-workgroup ticket
+    int32_t assoc_seq = 0;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
     // sharded correction: exchange slabs (own allocations, or caller-provided device buffers)
@@ -526,15 +529,30 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
     a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
     a.N = h->N; a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
+    const int32_t seq = ++h->assoc_seq == 0 ? ++h->assoc_seq : h->assoc_seq;       // never 0: that is the mapped copy's initial value
     {
         TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
-        HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_decision, h->storage,
-                                   h->stream));
+        HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_ticket, h->d_decision,
+                                   h->h_decision_dev, seq, h->storage, h->stream));
     }
-    HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
     if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
     if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    bool have = false;
+    if (h->h_decision_dev && !pos_cost && !sig_cost) {
+        // measure()'s path: the kernel writes the decision into mapped host memory (sequence number last, behind a system-scope
+        // fence); polling for it costs ~2 us after the kernel retires, a device->host copy + stream synchronisation ~15 us.
+        // Bounded: after ~2 ms the ordinary path below takes over.
+        volatile AssocDecision *hd = h->h_decision;
+        for (int spin = 0; spin < 2000000; ++spin) {
+            if (hd->seq == seq) { have = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (have) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!have) {
+        HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     *is_new = h->h_decision->is_new;
     *idx = h->h_decision->index;
     return EKF_OK;
@@ -716,6 +734,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));
     HIPCHK(h, dalloc(h, &h->d_partial, (size_t)((h->cap + kAssocBlock - 1) / kAssocBlock)));
     HIPCHK(h, dalloc(h, &h->d_decision, 1));
+    HIPCHK(h, dalloc(h, &h->d_ticket, 1));
     HIPCHK(h, dalloc(h, &h->d_pos_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_sig_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_digest, 4));
@@ -732,7 +751,13 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
             h->recv = h->own_recv;
         }
     }
-    HIPCHK(h, hipHostMalloc((void **)&h->h_decision, sizeof(AssocDecision), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_decision, sizeof(AssocDecision), hipHostMallocMapped));
+    memset(h->h_decision, 0, sizeof(AssocDecision));
+    {
+        static const bool poll = [] { const char *v = getenv("EKF_ASSOC_POLL"); return !v || atoi(v) != 0; }();
+        void *dp = nullptr;
+        if (poll && hipHostGetDevicePointer(&dp, h->h_decision, 0) == hipSuccess) h->h_decision_dev = (AssocDecision *)dp;
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
 
     // x = [0 0 0]; P = 0.1*eye(3)   (EKF_SLAM.m:28-31, EKF_SLAM_UC.m:29-32)

@@ -65,7 +65,7 @@ struct AssocArgs {
 struct AssocDecision {        // written by the device, read back by the host
     int64_t index;            // 0-based; == N for a new landmark
     int32_t is_new;
-    int32_t pad;
+    int32_t seq;              // launch sequence number, written LAST (the host may poll a mapped copy for it)
     double  min_ll;
 };
 
@@ -100,9 +100,13 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // kname: nullptr, or 64 bytes that receive the name of the kernel instance that was launched ("k_flush_mfma<double,128,8>")
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname);
-// pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries
+// pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries; ticket: a
+// device int, zero between launches (the last workgroup to finish reduces the partials and resets it: one launch, no
+// finishing kernel); decision: device copy; host_decision: nullptr or a host-MAPPED copy the kernel writes as well, its `seq`
+// field last, behind a system-scope fence (the host polls for seq == `seq`)
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
-                            AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s);
+                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
+                            int storage, hipStream_t s);
 // dense (column-major, n x n, device) <-> tiled
 hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s);
 hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s);

@@ -1111,7 +1111,8 @@ __device__ __forceinline__ bool assoc_better(double la, int64_t ia, double lb, i
 template <typename TS>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
-                                                           AssocDecision *__restrict__ partial) {
+                                                           AssocDecision *partial, int *ticket, AssocDecision *__restrict__ decision,
+                                                           AssocDecision *host_decision, int seq) {
     __shared__ double sh_ll[kAssocBlock];
     __shared__ int64_t sh_ix[kAssocBlock];
     const int tid = threadIdx.x;
@@ -1179,18 +1180,23 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         }
         __syncthreads();
     }
-    if (tid == 0) { partial[blockIdx.x].min_ll = sh_ll[0]; partial[blockIdx.x].index = sh_ix[0]; }
-}
-
-__global__ __launch_bounds__(kAssocBlock) void k_associate_finish(const AssocDecision *__restrict__ partial, int64_t nparts,
-                                                                  int64_t N, AssocDecision *__restrict__ decision) {
-    __shared__ double sh_ll[kAssocBlock];
-    __shared__ int64_t sh_ix[kAssocBlock];
-    const int tid = threadIdx.x;
-    double ll = INFINITY;
-    int64_t ix = INT64_MAX;
-    for (int64_t i = tid; i < nparts; i += kAssocBlock)
-        if (assoc_better(partial[i].min_ll, partial[i].index, ll, ix)) { ll = partial[i].min_ll; ix = partial[i].index; }
+    // The LAST workgroup to get here reduces the per-workgroup minima (one launch instead of two: the finishing kernel cost a
+    // launch and ~5 us in front of a host that waits for the decision)
+    __shared__ int last;
+    if (tid == 0) {
+        partial[blockIdx.x].min_ll = sh_ll[0]; partial[blockIdx.x].index = sh_ix[0];
+        __threadfence();                                             // the partial is visible before the ticket is drawn
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    ll = INFINITY; ix = INT64_MAX;
+    for (int64_t i = tid; i < (int64_t)gridDim.x; i += kAssocBlock) {
+        const double pl = ((volatile AssocDecision *)partial)[i].min_ll;
+        const int64_t pi = ((volatile AssocDecision *)partial)[i].index;
+        if (assoc_better(pl, pi, ll, ix)) { ll = pl; ix = pi; }
+    }
     sh_ll[tid] = ll; sh_ix[tid] = ix;
     __syncthreads();
     for (int s = kAssocBlock / 2; s > 0; s >>= 1) {
@@ -1201,10 +1207,20 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_finish(const AssocDec
     }
     if (tid == 0) {
         const bool found = sh_ix[0] != INT64_MAX;     // something passed the threshold (min_ll starts at Inf, :43)
-        decision->is_new = found ? 0 : 1;
-        decision->index = found ? sh_ix[0] : N;       // default index = numOfLandmarks + 1 (:40), 0-based here
-        decision->min_ll = sh_ll[0];
-        decision->pad = 0;
+        AssocDecision d;
+        d.is_new = found ? 0 : 1;
+        d.index = found ? sh_ix[0] : a.N;             // default index = numOfLandmarks + 1 (:40), 0-based here
+        d.min_ll = sh_ll[0];
+        d.seq = seq;
+        *decision = d;
+        *ticket = 0;                                  // ready for the next launch (stream order)
+        if (host_decision) {
+            // mapped host memory: payload first, then -- behind a system-scope fence -- the sequence number the host polls for
+            volatile AssocDecision *hd = host_decision;
+            hd->index = d.index; hd->is_new = d.is_new; hd->min_ll = d.min_ll;
+            __threadfence_system();
+            hd->seq = seq;
+        }
     }
 }
 
@@ -1765,14 +1781,14 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
-                            AssocDecision *partial, AssocDecision *decision, int storage, hipStream_t s) {
+                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
+                            int storage, hipStream_t s) {
     const int64_t grid = cdiv(a.N > 0 ? a.N : 1, kAssocBlock);
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial),
-        hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_associate_finish, dim3(1), dim3(kAssocBlock), 0, s, partial, grid, a.N, decision);
+        hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
+                           decision, host_decision, seq),
+        hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
+                           decision, host_decision, seq));
     return hipGetLastError();
 }
 

@@ -27,12 +27,18 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="replay the same inputs through the CPU oracle and compare")
+    ap.add_argument("--kernel-timing", action="store_true",
+                    help="bracket k_associate / k_gather with HIP events (adds ~2 us per launch: use for the per-kernel figures, not for "
+                         "the throughput line)")
+    ap.add_argument("--host-decision", action="store_true",
+                    help="cfg.device_assoc = 0: take the association decision from the host mirror of s (legitimate: the reference's "
+                         "live likelihood is signature-only, Correspondence.m:75); default here is the device kernels per observation")
     args = ap.parse_args()
     from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     N = args.landmarks
     _, run = make_run(N, 20260102, 2 + args.steps, policy="nearest", m=args.m)
-    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch)
+    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, device_assoc=not args.host_decision)
     lm = Landmark('SYNTHETIC')
     t0 = time.perf_counter()
     for u, scan in run[:2]:                      # warm-up sweep: appends every landmark
@@ -48,6 +54,10 @@ def main():
         idx, loc = lm.landmarkObj.table()
         feeds.append((u, obs, idx.copy(), loc.copy()))
     eng = e._e
+    from ekf_slam_amd import _lib as L
+    if args.kernel_timing:
+        eng.timing_enable(L.EKF_KERNEL_ASSOCIATE, True, launches=args.steps * args.m + 8)
+        eng.timing_enable(L.EKF_KERNEL_GATHER, True, launches=args.steps * args.m + 8)
     eng.sync()
     t0 = time.perf_counter()
     for u, obs, idx, loc in feeds:
@@ -55,14 +65,27 @@ def main():
         eng.measure(obs, u, idx, loc)
     eng.flush(); eng.sync()
     dt = time.perf_counter() - t0
+    n_as, ms_as = eng.timing_read(L.EKF_KERNEL_ASSOCIATE) if args.kernel_timing else (0, 0.0)
+    n_ga, ms_ga = eng.timing_read(L.EKF_KERNEL_GATHER) if args.kernel_timing else (0, 0.0)
     x_end = eng.get_x()
+    # k_associate: one lane per landmark reads its 3x2 strip block, its 2x2 diagonal block, x_j and s_k (+ the shared 3x3 robot
+    # block): 13 doubles = 104 B per landmark and observation -- ~100 KB per launch at 1 k landmarks, i.e. a
+    # latency-bound launch; the HBM roofline is quoted only to show how far from bandwidth-bound it is
+    assoc = None
+    if n_as:
+        b_assoc = 13 * 8 * N
+        t_as = ms_as / n_as * 1e-3
+        assoc = {"kernel": "k_associate + k_associate_finish", "launches": n_as, "avg_launch_us": t_as * 1e6,
+                 "algorithmic_bytes_per_launch": b_assoc, "achieved_GBps": b_assoc / t_as / 1e9,
+                 "roofline": {"bound": "latency", "hbm_frac": b_assoc / t_as / 8e12}}
     out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I−KH)P vs roofline",
            "value": args.steps * args.m / dt, "unit": "update-steps/s", "slam_iterations_per_s": args.steps / dt,
            "n_gpus": 1, "steps": args.steps, "ms_per_iteration": dt / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "configs[1]: %d landmarks, unknown correspondence (EKF_SLAM_UC.m + Correspondence.m), F64; "
                                   "iteration = predict + measure() over the %d nearest landmarks" % (N, args.m),
                       "deferred_batch": args.batch, "tile": args.tile, "warmup_sweep_s": t_sweep,
-                      "device_association": os.environ.get("EKF_FORCE_DEVICE_ASSOC", "0") == "1",
+                      "device_association": (not args.host_decision) or os.environ.get("EKF_FORCE_DEVICE_ASSOC", "0") == "1",
+                      "associate": assoc, "gather_avg_us": (ms_ga / n_ga * 1e3) if n_ga else None,
                       "state_finite": bool(np.isfinite(x_end).all())}}
     if args.check:
         from oracle.ekf_structured import StructuredEKF
