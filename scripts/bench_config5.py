@@ -62,13 +62,14 @@ def main():
     e_N = [N0]
     run(steps[:args.warmup])
     e.sync()
-    e.timing_enable(L.EKF_KERNEL_DOWNDATE, True)
+    e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=args.steps + 8)
     n_start = 3 + 2 * e_N[0]
     t0 = time.perf_counter()
     run(steps[args.warmup:])
     e.sync()
     dt = time.perf_counter() - t0
     launches, ms = e.timing_read(L.EKF_KERNEL_DOWNDATE)
+    kernel, kpairs = e.downdate_kernel_name()
     n_end = 3 + 2 * e_N[0]
     w_bytes = 4 if args.storage == "f32" else 8
     n_mid = (n_start + n_end) / 2
@@ -83,7 +84,7 @@ def main():
                       "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
                       "bulk_load_s": t_load, "state_finite": finite},
            "roofline": {"bound": "hbm", "achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": "k_flush_mfma<float,256>",
+                        "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": kernel, "pairs_per_launch": kpairs,
                         "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
                         "update_steps_per_launch": args.steps / max(launches, 1)}}
     print(json.dumps(out), flush=True)
