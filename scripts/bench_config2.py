@@ -75,7 +75,7 @@ def main():
     if n_as:
         b_assoc = 13 * 8 * N
         t_as = ms_as / n_as * 1e-3
-        assoc = {"kernel": "k_associate + k_associate_finish", "launches": n_as, "avg_launch_us": t_as * 1e6,
+        assoc = {"kernel": "k_associate", "launches": n_as, "avg_launch_us": t_as * 1e6,
                  "algorithmic_bytes_per_launch": b_assoc, "achieved_GBps": b_assoc / t_as / 1e9,
                  "roofline": {"bound": "latency", "hbm_frac": b_assoc / t_as / 8e12}}
     out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I−KH)P vs roofline",
