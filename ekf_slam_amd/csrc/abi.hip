@@ -729,17 +729,6 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     // ONE allocation, G pairs then K pairs: k_gather addresses both from one uniform base with 32-bit lane offsets
     HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap * 2));
     h->st.Kp = h->st.Gp + (size_t)(2 * ldm) * h->st.pcap;
-    h->st.Mp = nullptr; h->st.zpad = nullptr;
-    if ((h->storage == EKF_STORE_F64 && T == 128 && h->batch > 1) || (h->storage == EKF_STORE_F32 && T == 256)) {
-        // the configurations whose pass over P runs on the matrix cores (k_flush_mfma): planar copy of the pending pairs
-        HIPCHK(h, dalloc(h, &h->st.Mp, (size_t)(4 * ldm) * h->st.pcap));
-        double *zp = nullptr;
-        HIPCHK(h, dalloc(h, &zp, 256));
-        double zh[256];
-        for (int i = 0; i < 128; ++i) { zh[i] = 0.0; zh[128 + i] = -0.0; }
-        HIPCHK(h, hipMemcpy(zp, zh, sizeof zh, hipMemcpyHostToDevice));
-        h->st.zpad = zp;
-    }
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
     HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));
@@ -1111,7 +1100,6 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     if ((n - 3) / 2 < h->N) {  // shrinking the map: pair slots must read as zero beyond the active columns
         HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-        if (h->st.Mp) HIPCHK(h, hipMemsetAsync(h->st.Mp, 0, (size_t)h->st.pair_stride * 2 * h->st.pcap * 8, h->stream));
     }
     h->N = (n - 3) / 2;
     h->pf_valid = false;       // a prefetch belongs to the state it was taken from
@@ -1232,7 +1220,6 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     if (N < h->N) {
         HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-        if (h->st.Mp) HIPCHK(h, hipMemsetAsync(h->st.Mp, 0, (size_t)h->st.pair_stride * 2 * h->st.pcap * 8, h->stream));
     }
     h->N = N;
     h->s_host.assign(s, s + N);
@@ -1351,7 +1338,6 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     h->npend = 0; h->pstart = 0; h->pf_valid = false; h->have_pp = false;
     hipError_t e = hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
-    if (e == hipSuccess && h->st.Mp) e = hipMemsetAsync(h->st.Mp, 0, (size_t)h->st.pair_stride * 2 * h->st.pcap * 8, h->stream);
     if (e != hipSuccess) return done(fail(h, EKF_ERR_HIP, "checkpoint_load: clearing the pending pairs", e));
     std::vector<double> shost((size_t)hd.N);
     rc = stream_in(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);

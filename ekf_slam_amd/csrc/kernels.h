@@ -23,12 +23,6 @@ struct DevState {
     double *Kp;           // ... the pending K pairs: Kp = Gp + pcap * pair_stride (k_gather relies on a 32-bit offset between them)
     int64_t pair_stride;   // 2 * ldm
     int32_t pcap;          // slots in the ring
-    // The same pending pairs once more, in the form the matrix-core flush consumes: planar and K negated.  Ring slot i holds four
-    // rows of ldm doubles, [4i+0] = G(1,:), [4i+1] = G(2,:), [4i+2] = -K(:,1), [4i+3] = -K(:,2) -- a row IS one k-row of the MFMA
-    // operands, so k_flush_mfma stages it by LDS-DMA (global_load_lds, 16 B per lane, no registers, no LDS write pass).
-    // nullptr when the handle never runs the matrix-core flush (f64 tiles with batch 1, small test tiles).
-    double *Mp;
-    const double *zpad;    // 128 x +0.0 then 128 x -0.0: the k-rows that pad an odd pair count (x + (-0)(+0) == x for every x)
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
     int64_t ldm;       // strip leading dimension = landmark-block capacity rounded up to T
     TileMap tm;

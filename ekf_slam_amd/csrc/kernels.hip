@@ -927,10 +927,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
         Gout[c] = make_double2(g[0], g[1]);
         Kout[c] = make_double2(k0, k1);
-        if (st.Mp) {                                               // the matrix-core flush's operand rows (kernels.h): planar, K negated
-            double *__restrict__ mp = st.Mp + (int64_t)ring_slot(pstart, npend, st.pcap) * 4 * ldm + c;
-            mp[0] = g[0]; mp[ldm] = g[1]; mp[2 * ldm] = -k0; mp[3 * ldm] = -k1;
-        }
         x_nxt[3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
         double *__restrict__ sn = strip_nxt;
         sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
@@ -940,10 +936,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
-        if (st.Mp) {
-            double *__restrict__ mp = st.Mp + (int64_t)ring_slot(pstart, npend, st.pcap) * 4 * ldm + c;
-            mp[0] = 0.0; mp[ldm] = 0.0; mp[2 * ldm] = -0.0; mp[3 * ldm] = -0.0;
-        }
     }
 #ifdef EKF_GATHER_STAMPS
     EKF_STAMP();                                                  // 4: outputs issued
@@ -1544,7 +1536,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__
     }
 }
 
-// Batched flush on the matrix cores (f64 tiles, T = 128; f32 tiles, T = 256) -- the production flush for two or more pending pairs.
+// Batched flush on the matrix cores (f64 tiles, T = 128) -- the production flush for two or more pending pairs.
 // P_tile -= K_rows (64 x 2m) * G_cols (2m x 128) is a rank-2m update; v_mfma_f64_16x16x4_f64 applies four of its 2m
 // rank-1 terms per instruction.  The instruction is a k-ordered chain of correctly rounded FMAs,
 //     D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C))))
@@ -1553,66 +1545,35 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__
 // bit-identical to rank2_apply() applied pair after pair -- i.e. to the immediate (batch = 1) downdate.
 // Mapping: a workgroup owns 64 rows x 128 columns of a tile, a wavefront 16 rows x 128 columns = 8 accumulator blocks
 // (32 f64 per lane).  The MFMA "column" lane&15 of block (bp, e) is the PHYSICAL column 32*bp + 2*(lane&15) + e, so
-// every lane still loads / stores 16 contiguous bytes of a tile row.
-// Operand staging (round 2): the pending pairs also exist as planar k-rows with K already negated (DevState::Mp, written by
-// k_gather), so a chunk of kChunk pairs goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: one 1 KiB wave instruction = one
-// k-row of G, or two k-rows of -K) into a DOUBLE-BUFFERED image: no staging registers, no LDS write pass, the next chunk in
-// flight behind this chunk's MFMAs, one barrier per chunk.  Measured with the staging stubbed out (profiles/round2_tuning.md,
-// sweep 19): the register-staged form lost 0.045 ms of a 0.62 ms pass to it.  -K's k-rows are rotated by 16 rows per k index
-// (by the per-lane SOURCE address; the LDS image of a DMA is lane-linear) so that the four k-groups of a ds_read_b64 hit
-// different banks -- the job the 16-double row padding did for the register-staged image.
-// An odd pair count is padded with A = -0.0, B = +0.0 (x + (-0)(+0) == x for every x, signed zeros included), fetched from a
-// constant page (DevState::zpad).  Three wavefronts per SIMD: four and five were measured SLOWER (same sweep).
+// every lane still loads / stores 16 contiguous bytes of a tile row.  -K and G of a chunk of kChunk pairs are staged
+// through LDS once per workgroup, de-interleaved to [k][row] / [k][col]; the per-k-step cost is one ds_read_b64 (A)
+// and four ds_read_b128 (B) per 8 MFMAs.  An odd pair count is padded with A = -0.0, B = +0.0 (x + (-0) == x
+// for every x, signed zeros included).
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// global -> LDS, 16 bytes per lane, destination = wave-uniform LDS address + 16 * lane.  Inline asm, not
-// __builtin_amdgcn_global_load_lds: hipcc tracks the builtin as a pending LDS write and puts s_waitcnt vmcnt(0) in front of every
-// later ds_read -- which drains the chunks that are meant to stay in flight (measured: the pass got SLOWER than with register
-// staging).  An asm load is absent from the compiler's waitcnt bookkeeping; this kernel counts its completions itself
-// (wait_dma_then_barrier).  M0 carries the LDS base and is compiler-reserved: saved and restored inside the one statement.
-__device__ __forceinline__ void lds_dma16(const void *gsrc, const void *lds_wave_base) {
-    unsigned keep;
-    const unsigned lds_addr = (unsigned)(size_t)(const __attribute__((address_space(3))) void *)lds_wave_base;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
-}
-
-// s_waitcnt vmcnt(n) + s_barrier with n a run-time multiple of kPer (the immediate must be a constant: small switch).  Raw
-// s_barrier, NOT __syncthreads(): its fence would add vmcnt(0) and drain the chunks that are meant to stay in flight.
-template <int kPer>
-__device__ __forceinline__ void wait_dma_then_barrier(int chunks_in_flight) {
-    switch (chunks_in_flight) {
-        case 0:  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-        case 1:  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(kPer) : "memory"); break;
-        case 2:  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(2 * kPer) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(3 * kPer) : "memory"); break;
-    }
-}
-
-template <typename TS, int T, int kChunk, int kBufs>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// Two chunk sizes: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~24 pairs, where the pass is
+// HBM-bound and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond,
+// where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
+// Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
+// = 64 rows x one 128-column half; a lane's 16 bytes are 4 columns, widened to f64 on load and rounded once on store).
+template <typename TS, int T, int kChunk>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChunk <= 4 ? 4 : 3, kChunk <= 4 ? 4 : 3)))
 void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
-                  const double *__restrict__ Mp, const double *__restrict__ zpad, int64_t ldm, int pstart, int pcap,
+                  const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
                   int npairs, TileMap tm) {
-    constexpr int kRows = 64, kCols = 128;
+    constexpr int kRows = 64, kCols = 128, kKPad = kRows + 16;
     constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
     constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
     constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
-    constexpr int kK = 2 * kChunk;                                    // k-rows of a chunk
-    constexpr int kGper = kK / 4, kKper = kK / 8;                     // DMA instructions per wavefront and chunk: G k-rows, -K k-row pairs
-    constexpr int kPer = kGper + kKper;
-    constexpr int kAhead = kBufs - 1;                                 // chunks requested ahead of the one being applied
     static_assert(kBP * kE == 8 && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 columns = 8 MFMA blocks");
-    static_assert(kChunk % 4 == 0 && kBufs >= 2 && kBufs <= 4, "whole MFMA k-steps; equal DMA shares for 4 wavefronts");
-    static_assert((size_t)kBufs * kK * (kCols + kRows) * 8 <= 49152, "three workgroups per CU: 48 KiB of LDS each");
-    __shared__ __attribute__((aligned(16))) double Gs[kBufs][kK][kCols];
-    __shared__ __attribute__((aligned(16))) double Ks[kBufs][kK][kRows];
+    static_assert(kChunk % 2 == 0 && (kChunk * kCols) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
+    __shared__ __attribute__((aligned(16))) double Gs[2 * kChunk][kCols];
+    __shared__ double Ks[2 * kChunk][kKPad];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane >> 4, lc = lane & 15;                        // MFMA k / row-group index, MFMA row / column index
     const int64_t nitems = 8 * nwork * kSubsPerTile;                  // 8 per-XCD streams (see k_downdate_w)
-    const int nchunks = (npairs + kChunk - 1) / kChunk;
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
         const int64_t vi = it >> 3;
         const int64_t w = vi / kSubsPerTile;
@@ -1621,35 +1582,6 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
         if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
         const int slab = sub / kColParts, cpart = sub - slab * kColParts;
         const int row0 = slab * kRows + wave * 16;
-        const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
-        const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
-        // One chunk's DMA, this wavefront's share: G k-rows kGper*w .. (one 1 KiB instruction each: 128 columns) and -K k-row pairs
-        // (lanes 0-31 one k-row, lanes 32-63 the next, 64 rows = 512 B each).  Always kPer instructions (k-rows beyond the pair
-        // count come from the zero page): the counted vmcnt waits below rely on it.
-        auto stage = [&](int c) {
-            const int c0 = c * kChunk;
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            const int b = c % kBufs;
-            auto krow_src = [&](int kk, bool is_k) -> const double * {   // planar row of MFMA k index kk of this chunk, or the zero page
-                if (kk >= 2 * cn) return zpad + (is_k ? 128 : 0) - (is_k ? krow0 : gcol0);      // (the caller adds the offsets back)
-                return Mp + ((int64_t)ring_slot(pstart, c0 + (kk >> 1), pcap) * 4 + (is_k ? 2 : 0) + (kk & 1)) * ldm;
-            };
-#pragma unroll
-            for (int q = 0; q < kGper; ++q) {
-                const int kk = kGper * wave + q;
-                lds_dma16(krow_src(kk, false) + gcol0 + 2 * lane, &Gs[b][kk][0]);
-            }
-#pragma unroll
-            for (int q = 0; q < kKper; ++q) {
-                const int kb = 2 * (kKper * wave + q);                // first k-row of the pair this instruction fills
-                const int kk = kb + (lane >> 5);                      // per lane: the two halves of the wavefront take two k-rows
-                const int pos = 2 * (lane & 31);                      // LDS position (row slot) of this lane's 16 bytes in its k-row
-                const int row = (pos - 16 * (kk & 3)) & 63;           // rotation by 16 rows per k index: bank spread for the A reads
-                lds_dma16(krow_src(kk, true) + krow0 + row, &Ks[b][kb][0]);
-            }
-        };
-#pragma unroll
-        for (int c = 0; c < kAhead; ++c) if (c < nchunks) stage(c);
         const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + lr) * T + cpart * kCols + kE * lc;
         const TS *__restrict__ tp = tiles + toff;
         TS *__restrict__ td = dst + toff;
@@ -1661,35 +1593,58 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 #pragma unroll
                 for (int e = 0; e < kE; ++e)                          // adjacent scalars: one 16-byte nontemporal load
                     acc[bp][e][r] = (double)__builtin_nontemporal_load(tp + (int64_t)(4 * r) * T + 16 * kE * bp + e);
-        for (int c = 0; c < nchunks; ++c) {
-            const int c0 = c * kChunk;
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            const int b = c % kBufs;
-            // this wavefront's share of chunk c has landed, then the barrier: everyone's has, and everyone is done with chunk
-            // c - 1, whose buffer the stage() below overwrites.  At c = 0 the tile loads (issued after the first DMAs) are waited
-            // for as well; later the chunks c+1 .. stay in flight across the barrier.
-            {
-                int ahead = nchunks - 1 - c;
-                if (ahead > kAhead - 1) ahead = kAhead - 1;
-                wait_dma_then_barrier<kPer>(c == 0 ? 0 : ahead);
+        const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
+        const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
+        constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
+        double2 tg[kPerG], tk[kPerK];                                 // the NEXT chunk's operands, in flight while this one is applied
+        auto fetch = [&](int c0, int cn) {
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, col = e & (kCols - 1);
+                const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;      // clamp: always a valid pair, used only if in range
+                tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
             }
-            if (c + kAhead < nchunks) stage(c + kAhead);
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, row = e & (kRows - 1);
+                const int i = (e >> 6) < cn ? (e >> 6) : cn - 1;
+                tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
+            }
+        };
+        fetch(0, npairs < kChunk ? npairs : kChunk);
+        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
+            __syncthreads();                                          // everyone is done with the previous chunk
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
+                if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
+                else if (i == cn) { Gs[2 * i][col] = 0.0; Gs[2 * i + 1][col] = 0.0; }       // pad of an odd count
+            }
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, i = e >> 6, row = e & (kRows - 1);
+                if (i < cn) { Ks[2 * i][row] = -tk[q].x; Ks[2 * i + 1][row] = -tk[q].y; }
+                else if (i == cn) { Ks[2 * i][row] = -0.0; Ks[2 * i + 1][row] = -0.0; }
+            }
+            __syncthreads();
+            if (c0 + kChunk < npairs) fetch(c0 + kChunk, npairs - c0 - kChunk < kChunk ? npairs - c0 - kChunk : kChunk);
             const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
 #pragma unroll 2
             for (int ks = 0; ks < ksteps; ++ks) {
-                const double a = Ks[b][4 * ks + lr][(wave * 16 + lc + 16 * lr) & 63];
-                double2 bv[kBP][kE / 2];
+                const double a = Ks[4 * ks + lr][wave * 16 + lc];
+                double2 b[kBP][kE / 2];
 #pragma unroll
                 for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
                     for (int h = 0; h < kE / 2; ++h)
-                        bv[bp][h] = *reinterpret_cast<const double2 *>(&Gs[b][4 * ks + lr][16 * kE * bp + kE * lc + 2 * h]);
+                        b[bp][h] = *reinterpret_cast<const double2 *>(&Gs[4 * ks + lr][16 * kE * bp + kE * lc + 2 * h]);
 #pragma unroll
                 for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
                     for (int h = 0; h < kE / 2; ++h) {
-                        acc[bp][2 * h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].x, acc[bp][2 * h], 0, 0, 0);
-                        acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
+                        acc[bp][2 * h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].x, acc[bp][2 * h], 0, 0, 0);
+                        acc[bp][2 * h + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[bp][h].y, acc[bp][2 * h + 1], 0, 0, 0);
                     }
             }
         }
@@ -1700,7 +1655,6 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 #pragma unroll
                 for (int e = 0; e < kE; ++e)
                     __builtin_nontemporal_store((TS)acc[bp][e][r], td + (int64_t)(4 * r) * T + 16 * kE * bp + e);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (grid-stride callers) the operand buffers are free again
     }
 }
 
@@ -1722,19 +1676,17 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         // F32 tiles: also for a single pair -- the 64 x 128 work items stream the float tiles faster than the one-pair VALU kernel
         // (40 k landmarks: 4.4 ms vs 4.9 ms per pass); F64 tiles: the one-pair VALU kernel is the faster one (0.53 vs 0.56 ms)
         constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;
-        if (!use_mfma || npairs < kMinPairs || !work_xcd || xcd_len <= 0 || !st.Mp) return false;
+        if (!use_mfma || npairs < kMinPairs || !work_xcd || xcd_len <= 0) return false;
         constexpr int kSubs = (T / 64) * (T / 128);
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-        // operand pipeline: EKF_FLUSH_PIPE = "8x2" (8-pair chunks, double-buffered) | "4x4" (4-pair chunks, three ahead) | "4x2"
-        static const int pipe = [] { const char *v = getenv("EKF_FLUSH_PIPE"); return v ? atoi(v) : 44; }();
-#define EKF_FM(CH, NB) hipLaunchKernelGGL((k_flush_mfma<TS, T, CH, NB>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, \
-                                          (TS *)dstv, work_xcd, xcd_len, st.Mp, st.zpad, st.ldm, pstart, st.pcap, npairs, st.tm)
-        (void)chunk_switch;
-        if (pipe == 82) { EKF_FM(8, 2); name_kernel(kname, "k_flush_mfma", sizeof(TS), T, 8, -1); }
-        else if (pipe == 42) { EKF_FM(4, 2); name_kernel(kname, "k_flush_mfma", sizeof(TS), T, 4, -1); }
-        else { EKF_FM(4, 4); name_kernel(kname, "k_flush_mfma", sizeof(TS), T, 4, -1); }
-#undef EKF_FM
+        if (npairs <= chunk_switch)
+            hipLaunchKernelGGL((k_flush_mfma<TS, T, 4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        else
+            hipLaunchKernelGGL((k_flush_mfma<TS, T, 8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                               work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+        name_kernel(kname, "k_flush_mfma", sizeof(TS), T, npairs <= chunk_switch ? 4 : 8, -1);
         return true;
     } else {
         return false;
