@@ -11,6 +11,14 @@
 #define EKF_MHD inline
 #endif
 
+// These run on ONE wavefront in the latency chain of every update-step, where a taken-or-not branch costs more than both of its
+// sides: value selections are marked unpredictable so that the compiler emits v_cndmask instead of exec-mask branches.
+#if defined(__clang__)
+#define EKF_SEL(c) __builtin_unpredictable(c)
+#else
+#define EKF_SEL(c) (c)
+#endif
+
 namespace ekfm {
 
 constexpr double kD2R = 0.017453292519943295;
@@ -25,14 +33,17 @@ constexpr double kR2D = 57.29577951308232;
 // where a / 90 is within an ulp of k + 1/2, i.e. where |r| comes out at or just beyond 45; r = a - 90 n is exact for either
 // candidate, so ONE correction step restores exactly the n that round(a / 90) gives, ties (|r| == 45) included.
 EKF_MHD void reduce90(double a, double &r, int &quad) {
-    if (fabs(a) >= 1099511627776.0) a = fmod(a, 360.0);
+    if (!(fabs(a) < 1099511627776.0)) a = fmod(a, 360.0);        // rare; Inf / NaN come out as NaN and stay NaN below
     const double q = a * (1.0 / 90.0);
     double n = copysign(floor(fabs(q) + 0.5), q);
     r = fma(-90.0, n, a);
     // round-half-away-from-zero of the TRUE quotient: r must lie in [-45, 45], and a tie goes to the larger |n|
-    if (r > 45.0 || (r == 45.0 && a > 0.0)) { n += 1.0; r -= 90.0; }
-    else if (r < -45.0 || (r == -45.0 && a < 0.0)) { n -= 1.0; r += 90.0; }
-    quad = (int)(((long long)n) & 3);
+    const bool up = (r > 45.0) | ((r == 45.0) & (a > 0.0)), down = (r < -45.0) | ((r == -45.0) & (a < 0.0));
+    const double adj = EKF_SEL(up) ? 1.0 : (EKF_SEL(down) ? -1.0 : 0.0);
+    n += adj;
+    r = fma(-90.0, adj, r);                                       // exact (r -+ 90, or r itself)
+    // n mod 4 without a 64-bit integer conversion: n - 4 floor(n / 4) is an exact double in {0, 1, 2, 3}
+    quad = (int)(n - 4.0 * floor(n * 0.25));
 }
 
 // sin / cos on [-pi/4, pi/4] and atan on [0, inf): plain polynomial kernels instead of the libm routines.
@@ -125,15 +136,16 @@ EKF_MHD double cosd(double a) {
     return quad == 0 ? cos_pio4(t) : quad == 1 ? -sin_pio4(t) : quad == 2 ? -cos_pio4(t) : sin_pio4(t);
 }
 
-// sind and cosd of the same angle with one reduction and one sin/cos pair
+// sind and cosd of the same angle with one reduction and one sin/cos pair (non-finite angles give NaN through reduce90)
 EKF_MHD void sincosd(double a, double &sn, double &cs) {
-    if (!isfinite(a)) { sn = NAN; cs = NAN; return; }
     double r; int quad;
     reduce90(a, r, quad);
     const double t = kD2R * r;
     const double s0 = sin_pio4(t), c0 = cos_pio4(t);
-    sn = quad == 0 ? s0 : quad == 1 ? c0 : quad == 2 ? -s0 : -c0;
-    cs = quad == 0 ? c0 : quad == 1 ? -s0 : quad == 2 ? -c0 : s0;
+    // quad 0: (s, c)   1: (c, -s)   2: (-s, -c)   3: (-c, s)
+    const double sa = EKF_SEL(quad & 1) ? c0 : s0, ca = EKF_SEL(quad & 1) ? s0 : c0;
+    sn = EKF_SEL(quad & 2) ? -sa : sa;
+    cs = EKF_SEL((quad + 1) & 2) ? -ca : ca;
 }
 
 EKF_MHD double atan2d(double y, double x) { return atan2_poly(y, x) * kR2D; }

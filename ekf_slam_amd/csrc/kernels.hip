@@ -123,13 +123,15 @@ __device__ __forceinline__ void predict_common(double u0, double u1, double sn, 
 // (F*P)(i,c) for the 3x3 robot block from column c of P = (x0, x1, x2): rows 1, 2 pick up F(.,3) * P(3,c).  Operands by VALUE so
 // that a lane-parallel caller hands over values it selected, with no indexed access to a register array (scratch) or to LDS.
 __device__ __forceinline__ double predict_fp(int i, double x0, double x1, double x2, double fa, double fb) {
-    return i == 0 ? x0 + fa * x2 : i == 1 ? x1 + fb * x2 : x2;
+    const double r0 = x0 + fa * x2, r1 = x1 + fb * x2;           // both rows formed, then SELECTED (EKF_SEL: v_cndmask, no branches)
+    return EKF_SEL(i == 0) ? r0 : (EKF_SEL(i == 1) ? r1 : x2);
 }
 // entry (i,j) of F*Prr*F' + Q and of Q = (W*C)*W'  (EKF_SLAM.m:44,47); cj / c2 = columns j and 3 of Prr, wi / wj = W(i), W(j)
 __device__ __forceinline__ void predict_prr_entry(int i, int j, const double cj[3], const double c2[3], double fa, double fb, double wi,
                                                   double wj, double C, double &out, double &q) {
     const double m1 = predict_fp(i, cj[0], cj[1], cj[2], fa, fb), p2 = predict_fp(i, c2[0], c2[1], c2[2], fa, fb);
-    const double m2 = j == 0 ? m1 + fa * p2 : j == 1 ? m1 + fb * p2 : m1;                   // (F*P)*F'
+    const double c0 = m1 + fa * p2, c1 = m1 + fb * p2;
+    const double m2 = EKF_SEL(j == 0) ? c0 : (EKF_SEL(j == 1) ? c1 : m1);                   // (F*P)*F'
     q = (wi * C) * wj;
     out = m2 + q;
 }
@@ -506,6 +508,10 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {        // valu
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double lane_gather(double v, int src) {       // value of lane `src` (per-lane index): ds_bpermute x 2
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 // LDS traffic of ONE wavefront is ordered; this only keeps the compiler from moving accesses across it and drains the queue
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     __shared__ int diag_ready;                      // DIAG -> CHAIN: the patched 2x2 block is in pss[15..18]
     __shared__ int staged_cnt;                      // column wavefronts that have written their share of `upatch` (0..4)
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
+    __shared__ double2 dpatch[kMaxPending * 4];     // the same operands once more, staged by the DIAG wavefront for itself
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3 columns, 4 chain, 5 diag, 6 bearing
     const int lane = tid & 63;
@@ -564,6 +571,13 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         // below are known to be reset) and one at the end ("B").  In between the wavefronts meet through LDS flags only, each waiting
         // for exactly what it needs: CHAIN and BEARING for their own loads, DIAG for the column wavefronts' staging of `upatch`.
         double small_v = 0.0;
+        auto load_up_h = [&](int e0) {                                   // as the column path's load_up: clamped, unconditional
+            const int e = (do_patch && e0 < 4 * npend) ? e0 : 0;
+            const int i = e >> 2, which = e & 3;
+            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
+            return reinterpret_cast<const double2 *>(base)[j + (which & 1)];
+        };
+        double2 dup0 = make_double2(0.0, 0.0), dup1 = dup0;
         if (role == 4) {
             const double *sp = prr_cur;                                  // idle lanes re-read Prr(1,1), unused
             if (lane < 9) sp = prr_cur + lane;
@@ -583,6 +597,10 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
                 const int rr = t > b ? t : b, cc2 = t > b ? b : t;
                 small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
             }
+            // ... and the wave-uniform operands of the first 32 pending pairs (two per lane), so that the patch chain below does not
+            // wait for the column wavefronts' staging of `upatch` (it used to start ~1 000 clocks later and, at 16+ pending pairs,
+            // made the CHAIN wait for it)
+            dup0 = load_up_h(lane); dup1 = load_up_h(lane + 64);
         } else {
             small_v = x[lane < 3 ? lane : 3 + j + ((lane - 3) & 1)];       // BEARING: lanes 0..2 the pose, 3..4 the landmark
         }
@@ -596,27 +614,31 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             // ---- DIAG: canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so
             //      that the LDS latency is paid per group, not per pair
             if (do_patch && npend > 0) {
-                while (*(volatile int *)&staged_cnt < 4) { }          // the four column wavefronts have staged `upatch`
+                dpatch[lane] = dup0; dpatch[lane + 64] = dup1;        // pairs 0..31; more than 32 pending (asynchronous flush): the rest now
+                for (int e = 128 + lane; e < 4 * npend; e += 64) dpatch[e] = load_up_h(e);
                 wave_lds_sync();
+                EKF_STAMP();                                          // (probe, DIAG view) operands staged
                 if (lane < 3) {
                     const int q = lane;
                     const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
                     double d = pss[q == 0 ? 15 : q == 1 ? 17 : 18];
-                    for (int i0 = 0; i0 < npend; i0 += 8) {
+                    // the chain itself: two dependent FMAs per pending pair, in slot order; operands of 8 pairs read from LDS at a
+                    // time, whole groups first (no clamps, no selects in the chain), then the remainder pair by pair
+                    int i = 0;
+                    for (; i + 8 <= npend; i += 8) {
                         double2 kk[8], gg[8];
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) {
-                            const int ii = i0 + t < npend ? i0 + t : npend - 1;       // clamp: stay inside the staged entries
-                            kk[t] = upatch[4 * ii + ka]; gg[t] = upatch[4 * ii + ga];
-                        }
+                        for (int t = 0; t < 8; ++t) { kk[t] = dpatch[4 * (i + t) + ka]; gg[t] = dpatch[4 * (i + t) + ga]; }
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) { const double v = rank2_apply(d, kk[t], gg[t]); d = i0 + t < npend ? v : d; }
+                        for (int t = 0; t < 8; ++t) d = rank2_apply(d, kk[t], gg[t]);
                     }
+                    for (; i < npend; ++i) d = rank2_apply(d, dpatch[4 * i + ka], dpatch[4 * i + ga]);
                     if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
                 }
             }
             wave_lds_sync();                                              // the (patched) block is written ...
             if (lane == 0) *(volatile int *)&diag_ready = 1;              // ... before the flag (one wavefront: LDS order = program order)
+            EKF_STAMP();                                                  // (probe, DIAG view) flag set
         } else if (role == 6) {
             // ---- BEARING: nu = z - z_k, z_k = [sqrt(q); wrapTo360(atan2d(dy,dx) - heading)]  (EKF_SLAM.m:125-130,144), from the
             //      PREDICTED pose when predict is folded in -- same expressions as the chain wavefront's, so the same bits
@@ -642,10 +664,11 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             //      registers (static indices only: an array indexed by the lane would live in scratch memory) and SELECTS the ones
             //      its entry needs; what every lane needs identically (pose, H_s, inv(phi)) is computed redundantly; entries travel
             //      between lanes by v_readlane (G(:,S), phi) or, where each lane needs a different subset, through `pss` in LDS.
-            wave_lds_sync();                                          // own LDS writes above (one wavefront: in order)
+            // every lane gets the 20 operands this wavefront loaded (lane i holds operand i) by v_readlane: wave-uniform values, no
+            // LDS round trip; 15..18 (the landmark's own 2x2 block) belong to DIAG and are read later, from LDS
             double p[24];
 #pragma unroll
-            for (int i = 0; i < 24; ++i) p[i] = (i >= 15 && i < 19) ? 0.0 : pss[i];      // 15..18 belong to DIAG: read later, from LDS
+            for (int i = 0; i < 24; ++i) p[i] = (i >= 15 && i < 19) ? 0.0 : lane_bcast(small_v, i);
             double fa = 0.0, fb = 0.0;
             double pose[3] = { p[19], p[20], p[21] };
             if (kPredict) {
@@ -655,26 +678,28 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
                 const double sn = lane_bcast(sc_l.x, 0), cs = lane_bcast(sc_l.y, 0), sn2 = lane_bcast(sc_l.x, 1), cs2 = lane_bcast(sc_l.y, 1);
                 double W[3];
                 predict_common(pa.u0, pa.u1, sn, cs, fa, fb, W);
-                // lane l < 9: Prr'(l/3, l%3) and Q; 9..14: strip'(t, j+b), t = (l-9)>>1, b = (l-9)&1.  All lanes run both forms and
-                // keep theirs (no divergent branches: the two forms are a dozen operations each)
+                // lane l < 9: Prr'(l/3, l%3) and Q; 9..14: strip'(t, j+b), t = (l-9)>>1, b = (l-9)&1.  The three operands an entry needs
+                // (a column of Prr, or strip(0..2, j+b)) are GATHERED from the lanes that loaded them (small_v: lane i holds operand
+                // i) with ds_bpermute -- no LDS memory, no select chains -- and every lane runs both (short) forms, keeping its own
                 const int ei = lane >= 6 ? 2 : lane >= 3 ? 1 : 0, ej = lane - 3 * ei;
-                double cj[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) cj[k] = ej == 0 ? p[3 * k] : ej == 1 ? p[3 * k + 1] : p[3 * k + 2];
+                const int st_t = (lane - 9) >> 1, st_b = (lane - 9) & 1;
+                const bool is_prr = lane < 9;
+                const int g0 = is_prr ? ej : 9 + st_b, g1 = is_prr ? 3 + ej : 11 + st_b, g2 = is_prr ? 6 + ej : 13 + st_b;
+                const double v0 = lane_gather(small_v, g0 & 63), v1 = lane_gather(small_v, g1 & 63), v2 = lane_gather(small_v, g2 & 63);
+                const double cj[3] = { v0, v1, v2 };
                 const double c2[3] = { p[2], p[5], p[8] };
-                const double wi = ei == 0 ? W[0] : ei == 1 ? W[1] : W[2], wj = ej == 0 ? W[0] : ej == 1 ? W[1] : W[2];
+                const double wi = EKF_SEL(ei == 0) ? W[0] : (EKF_SEL(ei == 1) ? W[1] : W[2]);
+                const double wj = EKF_SEL(ej == 0) ? W[0] : (EKF_SEL(ej == 1) ? W[1] : W[2]);
                 double e_prr, e_q;
                 predict_prr_entry(ei, ej, cj, c2, fa, fb, wi, wj, pa.C, e_prr, e_q);
-                const int st_t = (lane - 9) >> 1, st_b = (lane - 9) & 1;
-                double s0 = st_b ? p[10] : p[9], s1 = st_b ? p[12] : p[11];
-                const double s2 = st_b ? p[14] : p[13];
-                predict_strip(s0, s1, s2, fa, fb);
-                const double e_strip = st_t == 0 ? s0 : st_t == 1 ? s1 : s2;
+                double s0 = v0, s1 = v1;
+                predict_strip(s0, s1, v2, fa, fb);
+                const double e_strip = EKF_SEL(st_t == 0) ? s0 : (EKF_SEL(st_t == 1) ? s1 : v2);
                 const double p0 = predict_pose_entry(pose, 0, pa.u0, pa.u1, sn2, cs2), p1 = predict_pose_entry(pose, 1, pa.u0, pa.u1, sn2, cs2),
                              p2 = predict_pose_entry(pose, 2, pa.u0, pa.u1, sn2, cs2);      // every lane (3 operations)
                 pose[0] = p0; pose[1] = p1; pose[2] = p2;
                 EKF_STAMP();                                          // (probe) entries formed
-                if (lane < 15) pss[lane] = lane < 9 ? e_prr : e_strip;    // the column lanes and the G(:,S) lanes read Prr', strip' from here
+                if (lane < 15) pss[lane] = EKF_SEL(is_prr) ? e_prr : e_strip;   // the column lanes and the G(:,S) lanes read Prr', strip' from here
                 if (lane < 9) ps.Q[lane] = e_q;
                 if (lane == 0) { ps.fa = fa; ps.fb = fb; }
             }
@@ -705,20 +730,21 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             const double phi[4] = { lane_bcast(e_phi, 0), lane_bcast(e_phi, 1), lane_bcast(e_phi, 2), lane_bcast(e_phi, 3) };
             ekfm::inv2(phi, so.Phi);                                  // :143 phi_k^-1 (every lane, redundantly)
             EKF_STAMP();                                              // 4: solve
-            // publish: H_s and inv(phi) from lane 0 (static indices), K_r and G_r one entry per lane (operands selected)
+            // publish: K_r and G_r are formed by every lane (18 operations, static indices, no divergent branches -- the per-lane
+            // form with its select chains was 200 instructions), then lane 0 stores the whole struct; nu is BEARING's
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                so.Gr[0][b] = GS[0][b]; so.Gr[1][b] = GS[1][b];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) so.Kr[b][cc] = solve_kr_entry(GS[0][b], GS[1][b], so.Phi[cc], so.Phi[2 + cc]);
+            }
             if (lane == 0) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) sol.Hs[i / 5][i % 5] = so.Hs[i / 5][i % 5];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sol.Phi[i] = so.Phi[i];
-            } else if (lane >= 14 && lane < 20) {
-                const int b = (lane - 14) >> 1, cc = (lane - 14) & 1;
-                const double g0b = b == 0 ? GS[0][0] : b == 1 ? GS[0][1] : GS[0][2], g1b = b == 0 ? GS[1][0] : b == 1 ? GS[1][1] : GS[1][2];
-                sol.Kr[b][cc] = solve_kr_entry(g0b, g1b, cc ? so.Phi[1] : so.Phi[0], cc ? so.Phi[3] : so.Phi[2]);
-            } else if (lane >= 20 && lane < 26) {
-                const int aa = (lane - 20) >= 3 ? 1 : 0, b = (lane - 20) - 3 * aa;
-                const double g0b = b == 0 ? GS[0][0] : b == 1 ? GS[0][1] : GS[0][2], g1b = b == 0 ? GS[1][0] : b == 1 ? GS[1][1] : GS[1][2];
-                sol.Gr[aa][b] = aa ? g1b : g0b;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { sol.Kr[i / 2][i % 2] = so.Kr[i / 2][i % 2]; sol.Gr[i / 3][i % 3] = so.Gr[i / 3][i % 3]; }
             }
         }
         __syncthreads();                                              // barrier B: sol, ps, pss complete
@@ -736,7 +762,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             } else {
                 if (lane < 6) { const int r = lane / 3, b = lane - 3 * r; st.small[3 * r + b] = sol.Gr[r][b]; }
                 else if (lane < 12) { const int b = (lane - 6) >> 1, r = (lane - 6) & 1; st.small[6 + 2 * b + r] = sol.Kr[b][r]; }
-#if !defined(EKF_GATHER_STAMPS) || EKF_GATHER_STAMPS != 2                 // (that probe build returns the chain's stamps in the Q slots)
+#if !defined(EKF_GATHER_STAMPS) || EKF_GATHER_STAMPS < 2                  // (those probe builds return a helper's stamps in the Q slots)
                 else if (kPredict && lane < 21) st.small[12 + (lane - 12)] = ps.Q[lane - 12];
 #endif
             }
@@ -745,6 +771,9 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         EKF_STAMP();                                                  // barrier B passed
 #if EKF_GATHER_STAMPS == 2                                                // the CHAIN wavefront's view (the Q slots hold one view per build)
         if (blockIdx.x == 0 && tid == kGatherCols) for (int i = 0; i < 9; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
+#endif
+#if EKF_GATHER_STAMPS == 3                                                // the DIAG wavefront's view
+        if (blockIdx.x == 0 && tid == kGatherCols + 64) for (int i = 0; i < 9; ++i) st.small[12 + i] = (double)(stamp[i] - stamp[0]);
 #endif
 #endif
         return;

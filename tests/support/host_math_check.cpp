@@ -55,6 +55,21 @@ int main(int argc, char **argv) {
             for (int s = 0; s < 3; ++s) { if (!same_reduce(a)) ++bad; a = nextafter(a, -INFINITY); }
         }
     for (double a : { 1e-300, -1e-300, 4.9e-324, 44.99999999999999, 45.00000000000001, 1e9 + 45.0, -1e9 - 45.0, 1.0e12 }) if (!same_reduce(a)) ++bad;
+    // sincosd == (sind, cosd), bit for bit, every quadrant and sign, and NaN for non-finite angles
+    for (int i = 0; i < n / 4; ++i) {
+        const double a = ang(rng);
+        double sn, cs;
+        ekfm::sincosd(a, sn, cs);
+        if (sn != ekfm::sind(a) || cs != ekfm::cosd(a) || std::signbit(sn) != std::signbit(ekfm::sind(a)) || std::signbit(cs) != std::signbit(ekfm::cosd(a))) ++bad;
+    }
+    for (int k = -16; k <= 16; ++k) {
+        double sn, cs;
+        ekfm::sincosd(45.0 * k, sn, cs);
+        if (sn != ekfm::sind(45.0 * k) || cs != ekfm::cosd(45.0 * k)) ++bad;
+    }
+    { double sn, cs; ekfm::sincosd(INFINITY, sn, cs); if (!std::isnan(sn) || !std::isnan(cs)) ++bad;
+      ekfm::sincosd(NAN, sn, cs); if (!std::isnan(sn) || !std::isnan(cs)) ++bad;
+      ekfm::sincosd(3.0e12 + 90.0, sn, cs); if (sn != ekfm::sind(3.0e12 + 90.0) || cs != ekfm::cosd(3.0e12 + 90.0)) ++bad; }
     printf("%.4f %.4f %.4f %.4f %d\n", ms, mc, ma, ma2, bad);
     return 0;
 }
