@@ -684,7 +684,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         HIPCHK(h, dalloc(h, &tiles, (size_t)slots * T * T * elt_size(h)));
         h->st.tiles = tiles;
         h->tilebuf[0] = tiles;
-        h->async_flush = cfg->async_flush != 0 && cfg->batch > 1;
+        h->async_flush = cfg->async_flush != 0;      // batch 1 too: the pass of update-step i then runs beside the gather of i + 1
         if (h->async_flush) {
             char *tiles2 = nullptr;
             HIPCHK(h, dalloc(h, &tiles2, (size_t)slots * T * T * elt_size(h)));

@@ -68,11 +68,13 @@ typedef struct ekf_config {
                                     pairs (the rows later corrections need are patched on the fly) and applied
                                     to P in ONE pass; results are bit-identical to batch = 1.  0 or 1 = every
                                     correction rewrites P immediately (EKF_SLAM.m:145 as written); max 64  */
-    int32_t async_flush;         /* with batch > 1: run each pass over P on a second stream, from the current tile
-                                    store into a second one (2x tile memory), while the next corrections go on
-                                    reading the current store plus all pending pairs; stores swap at the next
-                                    batch boundary.  Same bits as async_flush = 0.  The second stream is confined
-                                    to a CU mask that leaves 32 CUs (EKF_ASYNC_RESERVE_CUS) to the corrections. */
+    int32_t async_flush;         /* run each pass over P on a second stream, from the current tile store into a
+                                    second one (2x tile memory), while the next corrections go on reading the current
+                                    store plus all pending pairs; stores swap at the next batch boundary.  With
+                                    batch = 1 that is the as-written update-step software-pipelined: the pass of step i
+                                    beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
+                                    async_flush = 0.  The second stream is confined to a CU mask that leaves 32 CUs
+                                    (EKF_ASYNC_RESERVE_CUS) to the corrections. */
     int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure: 1 = every observation runs the association kernels on the device
                                     (per-landmark phi_k, Mahalanobis and signature cost, arg-min: Correspondence.m:49-87 as
                                     the reference evaluates it).  0 (default) = when w_pos == 0 the decision is taken from

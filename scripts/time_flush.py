@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--storage", default="f64")
     ap.add_argument("--label", default="")
+    ap.add_argument("--async-flush", action="store_true")
     a = ap.parse_args()
     import bench
     from ekf_slam_amd import Engine, _lib as L
@@ -31,7 +32,7 @@ def main():
     w, x, s, d, U = bench.make_state(N, 20260104)
     nsteps = a.batch * a.batches
     steps = bench.make_steps(w, N, a.batch * 2 + nsteps, [.01, 5.0])
-    e = Engine(capacity=N, tile=a.tile, batch=a.batch, storage=a.storage)
+    e = Engine(capacity=N, tile=a.tile, batch=a.batch, storage=a.storage, async_flush=a.async_flush)
     e.load_lowrank_state(x, s, d, U)
     warm, timed = e.marshal_steps(steps[:a.batch * 2]), e.marshal_steps(steps[a.batch * 2:])
     for i in range(warm["m"]):
