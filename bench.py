@@ -339,7 +339,7 @@ def main():
                        "shard": "tile (I,J) on rank (I+J) mod %d" % world, "transport": head["transport"],
                        "exchange": "none" if world == 1 else "one all-gather of the 2 x 2N row-panel per update-step",
                        "backend": backend if world > 1 else "none",
-                       "conditioning_steps": conditioning["steps"],
+                       "conditioning_steps": conditioning["steps"], "async_flush": bool(args.async_flush),
                        "state_finite": head["state_finite"],
                        # trace / sum / sum of squares of the final P (lower triangle): the same workload gives the same
                        # digest on 1, 2, 4 or 8 GPUs (to summation order)

@@ -387,11 +387,8 @@ int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
 
 constexpr int kThrottle = 48;
 
-int32_t finish_step(ekf_handle *h) {
-    h->cur ^= 1;
-    h->npend += 1;
-    const int32_t rc = (h->npend - h->nfrozen) >= h->batch ? batch_complete(h) : EKF_OK;
-    if (rc) return rc;
+// run-ahead throttle (see ekf_handle::throttle_ev): called once per update-step
+int32_t throttle_step(ekf_handle *h) {
     if (++h->since_mark >= kThrottle) {
         h->since_mark = 0;
         const int k = h->throttle_k;
@@ -402,6 +399,14 @@ int32_t finish_step(ekf_handle *h) {
         h->throttle_k = k ^ 1;
     }
     return EKF_OK;
+}
+
+int32_t finish_step(ekf_handle *h) {
+    h->cur ^= 1;
+    h->npend += 1;
+    const int32_t rc = (h->npend - h->nfrozen) >= h->batch ? batch_complete(h) : EKF_OK;
+    if (rc) return rc;
+    return throttle_step(h);
 }
 
 void fill_correct_args(ekf_handle *h, CorrectArgs &a, const double z[2], const double R[4], int64_t idx) {
@@ -506,11 +511,22 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     if (rc) return rc;
     CorrectArgs a;
     fill_correct_args(h, a, z, R, idx);
+    // small maps (one workgroup covers every column), every correction rewriting P at once: the downdate runs inside the gather
+    // kernel -- one launch per update-step instead of two (EKF_FUSE_SMALL=0: always two)
+    static const bool fuse_small = [] { const char *v = getenv("EKF_FUSE_SMALL"); return !v || atoi(v) != 0; }();
+    const bool fused = fuse_small && h->batch == 1 && !h->async_flush && h->npend == 0 && a.n_mm <= gather_fuse_max_rows() &&
+                       ekf_tiles_for(a.n_mm, h->T) * h->T <= 256;
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
-        HIPCHK(h, launch_gather(h->st, a, fuse, h->storage, h->stream));
+        HIPCHK(h, launch_gather(h->st, a, fuse, h->storage, h->stream, fused));
         h->have_pp = false;
+    }
+    if (fused) {                     // the pair never became pending: nothing to flush, only the double buffers flip
+        h->cur ^= 1;
+        snprintf(h->dd_kernel, sizeof h->dd_kernel, "k_gather<%s,fused downdate>", h->storage == EKF_STORE_F64 ? "double" : "float");
+        h->dd_pairs = 1;
+        return throttle_step(h);
     }
     return finish_step(h);
 }

@@ -74,8 +74,11 @@ constexpr int kAssocBlock = 256;
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
 hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s);
 // fused_predict != nullptr folds predict(u) into the correction (one launch instead of two, identical arithmetic)
+// fuse_downdate: the kernel also applies its pair to the landmark block (small maps: a.n_mm <= gather_fuse_max_rows(), one
+// workgroup); the pair is then NOT written to the pending ring and no downdate launch must follow
 hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
-                         hipStream_t s);
+                         hipStream_t s, bool fuse_downdate);
+int gather_fuse_max_rows();
 // sharded correction: (1) every shard copies the chunks of the landmark row-panel P(j:j+1,:) it owns into `send`
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.

@@ -515,7 +515,13 @@ __device__ __forceinline__ double lane_gather(double v, int src) {       // valu
 // LDS traffic of ONE wavefront is ordered; this only keeps the compiler from moving accesses across it and drains the queue
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename TS, bool kSharded, bool kPredict>
+// kFused (small maps, unsharded, batch 1: the whole landmark block fits ONE workgroup's columns): the rank-2 downdate of
+// EKF_SLAM.m:145 runs at the end of this kernel instead of in a launch of its own -- same arithmetic (rank2_apply per element), one
+// launch per update-step instead of two; the pair is handed over in LDS and never goes to the pending ring.
+constexpr int kFuseMaxRows = 48;                     // landmark-block rows (24 landmarks) up to which the fused form is used (beyond: slower than two launches)
+constexpr int kFuseElems = kFuseMaxRows * kFuseMaxRows / 256;     // elements of the block per column lane, all in flight together
+
+template <typename TS, bool kSharded, bool kPredict, bool kFused = false>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
@@ -947,24 +953,58 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     const int64_t out_off = (int64_t)ring_slot(pstart, npend, st.pcap) * st.pair_stride;   // this correction's own pair
     double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + out_off);
     double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + out_off);
+    double g[2] = { 0.0, 0.0 }, k0 = 0.0, k1 = 0.0;
     if (live) {
         if (kPredict) predict_strip(s0, s1, s2, ps.fa, ps.fb);
-        double g[2];
         for (int r = 0; r < 2; ++r)
             g[r] = sol.Hs[r][0] * s0 + sol.Hs[r][1] * s1 + sol.Hs[r][2] * s2 + sol.Hs[r][3] * m0 + sol.Hs[r][4] * m1;
-        const double k0 = g[0] * sol.Phi[0] + g[1] * sol.Phi[2];
-        const double k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
-        Gout[c] = make_double2(g[0], g[1]);
-        Kout[c] = make_double2(k0, k1);
+        k0 = g[0] * sol.Phi[0] + g[1] * sol.Phi[2];
+        k1 = g[0] * sol.Phi[1] + g[1] * sol.Phi[3];
+        if (!kFused) {
+            Gout[c] = make_double2(g[0], g[1]);
+            Kout[c] = make_double2(k0, k1);
+        }
         x_nxt[3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
         double *__restrict__ sn = strip_nxt;
         sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
         sn[ldm + c] = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
         sn[2 * ldm + c] = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
-    } else if (c < pad_end) {
+    } else if (c < pad_end && !kFused) {
         // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
+    }
+    if (kFused) {
+        // P = (I - K H) P on the landmark block, here: one workgroup holds every K(r,:) and G(:,c).  K goes through LDS (`upatch` is
+        // free: the patches that read it are behind barrier B; the helper wavefronts have left, a barrier counts live wavefronts
+        // only), G(:,c) is this lane's own.  Lane c walks down column c from the first row of its diagonal tile (diagonal tiles are
+        // updated whole, like k_downdate does); rows / columns beyond n_mm hold K = G = 0 there and are left alone -- same bits.
+        upatch[tid] = make_double2(k0, k1);
+        upatch[kGatherCols + tid] = make_double2(g[0], g[1]);
+        __syncthreads();
+        {
+            // all 256 lanes share the n x n elements (element e = tid + 256 q -> row e / n, column e % n); a lane requests all of
+            // its elements before it touches any (a serial walk down one column paid a memory round trip per row: measured
+            // SLOWER than two launches).  Stored elements: tile (I,J) with I >= J, diagonal tiles whole.
+            TS *__restrict__ tw = (TS *)st.tiles;
+            const int sh = st.tm.shift, msk = st.tm.T - 1;
+            const unsigned n = (unsigned)a.n_mm, total = n * n;
+            TS *ptr[kFuseElems];
+            double val[kFuseElems];
+            unsigned rr[kFuseElems], cq[kFuseElems];
+#pragma unroll
+            for (int q = 0; q < kFuseElems; ++q) {
+                const unsigned e = (unsigned)tid + 256u * q;
+                const unsigned r = e / n, cx = e - r * n;
+                const bool stored = e < total && (r >> sh) >= (cx >> sh);
+                rr[q] = stored ? r : 0u; cq[q] = stored ? cx : 0u;
+                ptr[q] = stored ? tw + st.tm.tile_offset(r >> sh, cx >> sh) + ((r & msk) << sh) + (cx & msk) : nullptr;
+                val[q] = stored ? (double)*ptr[q] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kFuseElems; ++q)
+                if (ptr[q]) *ptr[q] = (TS)rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]);
+        }
     }
 #ifdef EKF_GATHER_STAMPS
     EKF_STAMP();                                                  // 4: outputs issued
@@ -1394,6 +1434,8 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+int gather_fuse_max_rows() { return kFuseMaxRows; }
+
 // ---------------------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------------------
@@ -1426,16 +1468,22 @@ hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, h
 }
 
 hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
-                         hipStream_t s) {
+                         hipStream_t s, bool fuse_downdate) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kGatherCols);
     PanelView pv;
     pv.recv = nullptr; pv.slab = 0; pv.offset = 0; pv.Ij = 0; pv.patched = 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
-#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
-    if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
-    else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
+#define EKF_G(TS_, PRED_, FUSE_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_, FUSE_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
+    if (fuse_downdate) {
+        if (a.n_mm > kFuseMaxRows || grid != 1) return hipErrorInvalidValue;
+        if (storage == 0) { if (fused_predict) EKF_G(double, true, true); else EKF_G(double, false, true); }
+        else              { if (fused_predict) EKF_G(float, true, true); else EKF_G(float, false, true); }
+    } else {
+        if (storage == 0) { if (fused_predict) EKF_G(double, true, false); else EKF_G(double, false, false); }
+        else              { if (fused_predict) EKF_G(float, true, false); else EKF_G(float, false, false); }
+    }
 #undef EKF_G
     return hipGetLastError();
 }

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--storage", default="f64")
     ap.add_argument("--label", default="")
     ap.add_argument("--async-flush", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels: the throughput column is then undisturbed")
     a = ap.parse_args()
     import bench
     from ekf_slam_amd import Engine, _lib as L
@@ -38,8 +39,9 @@ def main():
     for i in range(warm["m"]):
         e.step_raw(warm, i)
     e.flush(); e.sync()
-    e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=nsteps + 8)
-    e.timing_enable(L.EKF_KERNEL_GATHER, True, launches=nsteps + 8)
+    if not a.no_kernel_timing:
+        e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=nsteps + 8)
+        e.timing_enable(L.EKF_KERNEL_GATHER, True, launches=nsteps + 8)
     e.sync()
     t0 = time.perf_counter()
     for i in range(timed["m"]):
@@ -53,7 +55,7 @@ def main():
     b_alg = (8 if a.storage == "f64" else 4) * n * (n + 1)
     avg = ms / max(nl, 1)
     print(json.dumps({"label": a.label, "landmarks": N, "batch": a.batch, "kernel": name, "pairs": pairs, "launches": nl,
-                      "flush_ms": round(avg, 4), "frac": round(b_alg / (avg * 1e-3) / 8e12, 4),
+                      "flush_ms": round(avg, 4), "frac": round(b_alg / (avg * 1e-3) / 8e12, 4) if avg > 0 else None,
                       "gather_us": round(gms / max(ng, 1) * 1e3, 2), "steps_per_s": round(nsteps / dt),
                       "finite": bool(np.isfinite(e.get_x()).all())}), flush=True)
     e.close()

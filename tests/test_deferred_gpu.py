@@ -268,3 +268,41 @@ def test_marshalled_steps_equal_plain_calls():
         b.step_raw(run, i)
     np.testing.assert_array_equal(a.get_x(), b.get_x())
     np.testing.assert_array_equal(a.get_P(), b.get_P())
+
+
+@pytest.mark.parametrize("tile", [16, 128])
+def test_small_map_fused_downdate_equals_the_two_launch_form_bitwise(tile, oracle_lib):
+    """Up to 24 landmarks an immediate-mode correction applies its rank-2 downdate inside the gather kernel (one launch per
+    update-step); beyond, and in deferred mode, k_downdate / the flush does it.  Same arithmetic, so a batch-1 engine growing
+    from 18 to 28 landmarks (fused, then two launches) must equal a batch-3 engine (never fused) bit for bit, and the oracle
+    to 1e-6."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 18
+    x, P, s = _state(N, 47)
+    imm = Engine(capacity=40, tile=tile, batch=1)
+    dfr = Engine(capacity=40, tile=tile, batch=3)
+    ref = StructuredEKF(40, "known")
+    for e in (imm, dfr, ref):
+        e.set_state(x, P, s)
+    rng = np.random.default_rng(9)
+    fused_seen = split_seen = False
+    for step in range(40):
+        u = [0.1, 3.0]
+        for e in (imm, dfr, ref):
+            e.predict(u)
+        idx0 = int(rng.integers(0, imm.N))
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        imm.correct(z, R, idx0); dfr.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+        name, _ = imm.downdate_kernel_name()
+        fused_seen |= "fused" in name
+        split_seen |= "fused" not in name
+        if step % 4 == 1 and imm.N < 28:
+            pos, sig = rng.uniform(-5, 5, 2), imm.N + 1
+            for e in (imm, dfr, ref):
+                e.append(u, R, pos, sig)
+    assert fused_seen and split_seen and imm.N == 28
+    np.testing.assert_array_equal(imm.get_x(), dfr.get_x())
+    np.testing.assert_array_equal(imm.get_P(), dfr.get_P())
+    assert rel_err(imm.get_P(), ref.P) < REL and rel_err(imm.get_x(), ref.x) < REL
