@@ -52,3 +52,32 @@ def test_checkpoint_refuses_mismatched_handle(tmp_path):
     ok = Engine(capacity=8, tile=16)
     ok.checkpoint_load(tmp_path / "a.ckpt")
     np.testing.assert_array_equal(ok.get_P(), e.get_P())
+
+
+def test_truncated_checkpoint_is_rejected_before_any_state_changes(tmp_path):
+    """A file whose length does not match its header (a torn write) must be refused BEFORE the handle's x, s, P or landmark
+    count are touched -- not discovered by a short read half-way through the load."""
+    from ekf_slam_amd import Engine, EkfError, _lib as L
+    rng = np.random.default_rng(3)
+    src = Engine(capacity=12, tile=16)
+    for k in range(5):
+        src.append([0.1, 1.0], np.diag([0.1, 3.0]), rng.uniform(-3, 3, 2), k + 1)
+    src.checkpoint_save(tmp_path / "full.ckpt")
+    blob = (tmp_path / "full.ckpt").read_bytes()
+    dst = Engine(capacity=12, tile=16)
+    dst.append([0.2, 2.0], np.diag([0.2, 5.0]), [9.0, 9.0], 1)
+    dst.correct([3.0, 30.0], np.diag([0.03, 150.0]), 0)
+    x0, P0, N0 = dst.get_x(), dst.get_P(), dst.N
+    for cut in (len(blob) - 8, len(blob) // 2, 64 + 16, 70):           # tail, middle, inside x, inside the header's first section
+        (tmp_path / "cut.ckpt").write_bytes(blob[:cut])
+        with pytest.raises(EkfError) as ei:
+            dst.checkpoint_load(tmp_path / "cut.ckpt")
+        assert ei.value.status == L.EKF_ERR_STATE
+        assert dst.N == N0
+        np.testing.assert_array_equal(dst.get_x(), x0)
+        np.testing.assert_array_equal(dst.get_P(), P0)
+    (tmp_path / "long.ckpt").write_bytes(blob + b"\0" * 8)            # trailing garbage is a mismatch too
+    with pytest.raises(EkfError):
+        dst.checkpoint_load(tmp_path / "long.ckpt")
+    dst.checkpoint_load(tmp_path / "full.ckpt")                       # and the handle is still usable
+    np.testing.assert_array_equal(dst.get_P(), src.get_P())
