@@ -1,0 +1,129 @@
+"""GPU: edge cases of the reference's path, each against the literal-dense oracle on the same inputs (1e-6) -- the cases a reader
+of EKF_SLAM.m / Correspondence.m would try to break it with: a bearing of exactly 0 (R(2,2) = 0, EKF_SLAM.m:108), an empty scan,
+the same landmark twice in one scan, a full (non-diagonal) R that sends the 2x2 inverse through its pivoting branch
+(EKF_SLAM.m:143), a landmark exactly at the robot (q = 0: the reference divides by zero -- non-finite state, not a crash), the
+heading wrapped at exactly 360 (wrapTo360(360) = 360), capacity reached exactly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-6
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _pair(N, seed, tile=16, batch=1, mode="known"):
+    from ekf_slam_amd import Engine
+    from oracle import ekf_dense as D
+    rng = np.random.default_rng(seed)
+    n = 3 + 2 * N
+    x = np.concatenate([[0.4, -0.3, 25.0], rng.uniform(-8, 8, 2 * N)])
+    U = rng.normal(0, 0.05, (n, 5))
+    P = np.diag(rng.uniform(0.01, 0.1, n)) + U @ U.T
+    s = list(range(1, N + 1))
+    e = Engine(mode=mode, capacity=N + 4, tile=tile, batch=batch)
+    e.set_state(x, P, np.array(s, dtype=float))
+    d = (D.EKF_SLAM if mode == "known" else D.EKF_SLAM_UC)()
+    d.x, d.P, d.s = x.copy(), P.copy(), list(s)
+    return e, d
+
+
+class _Table:
+    """Landmark.m-shaped source that hands the oracle the same observed rows / table the GPU gets."""
+    def __init__(self, rows, index, loc):
+        class _E:
+            def __init__(self, i, l): self.index, self.loc = i, np.asarray(l, dtype=float)
+        class _O: pass
+        self.rows = np.asarray(rows, dtype=float).reshape(-1, 3)
+        self.landmarkObj = _O()
+        self.landmarkObj.landmark = [_E(i, l) for i, l in zip(index, loc)]
+
+    def getLandmark(self, laser, x):
+        return self.rows
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_zero_bearing_gives_singular_R_and_still_matches(batch):
+    e, d = _pair(6, 1, batch=batch)
+    rows = [[5.0, 0.0, 1.0], [3.0, 0.0, 2.0], [7.5, 120.0, 3.0]]          # R = diag(r * .01, 0) for the first two rows
+    idx, loc = np.arange(1, 7.0), np.zeros((6, 2))
+    u = [0.1, 3.0]
+    e.predict(u); d.predict(u)
+    e.measure(rows, u, idx, loc); d.measure(None, u, _Table(rows, idx, loc))
+    assert np.isfinite(d.x).all()
+    assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
+
+
+def test_empty_scan_is_a_no_op_and_duplicates_are_applied_in_order():
+    e, d = _pair(5, 2, batch=3)
+    u = [0.2, -4.0]
+    e.predict(u); d.predict(u)
+    x0 = e.get_x()
+    e.measure(np.zeros((0, 3)), u, np.arange(1, 6.0), np.zeros((5, 2)))
+    np.testing.assert_array_equal(e.get_x(), x0)
+    # known correspondence corrects landmark ii = the ROW NUMBER (EKF_SLAM.m:123): rows 1..3 with repeated third columns
+    rows = [[4.0, 10.0, 2.0], [4.1, 11.0, 2.0], [6.0, 200.0, 1.0]]
+    idx, loc = np.arange(1, 6.0), np.zeros((5, 2))
+    e.measure(rows, u, idx, loc); d.measure(None, u, _Table(rows, idx, loc))
+    assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
+
+
+def test_full_R_takes_the_pivoting_branch_of_the_2x2_inverse():
+    from oracle.matlab_compat import inv2
+    e, d = _pair(4, 3)
+    R = np.array([[1e-4, 9.0], [9.0, 2e-4]])                              # |phi(2,1)| > |phi(1,1)|: rows swap in the LU
+    z = [6.0, 75.0]
+    e.predict([0.1, 2.0]); d.predict([0.1, 2.0])
+    from oracle.ekf_dense import _innovation_terms
+    _, H = _innovation_terms(d.x, 2)
+    phi = H @ d.P @ H.T + R
+    assert abs(phi[1, 0]) > abs(phi[0, 0])                                # the case is what it claims to be
+    np.testing.assert_allclose(inv2(phi), np.linalg.inv(phi), rtol=1e-12)
+    e.correct(z, R, 1); d._correct(z, R, 2)
+    assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
+
+
+def test_landmark_at_the_robot_divides_by_zero_like_the_reference(oracle_lib):
+    """q = 0 (EKF_SLAM.m:127,137): MATLAB's 1/q_k is Inf and the update turns x and P into NaN / Inf without an error.  Checked
+    against the structured C restatement (IEEE division; the NumPy one raises on a Python float division)."""
+    from oracle.ekf_structured import StructuredEKF
+    e, d = _pair(3, 4)
+    x = d.x.copy(); x[5:7] = x[0:2]                                       # landmark 2 exactly at the robot
+    ref = StructuredEKF(8, "known")
+    e.set_state(x, d.P, np.arange(1, 4.0)); ref.set_state(x, d.P, np.arange(1, 4.0))
+    z, R = [1.0, 10.0], np.diag([0.01, 50.0])
+    e.correct(z, R, 1); ref.correct(z, R, 2)
+    xe, xr = e.get_x(), ref.x
+    assert not np.isfinite(xr).any() and not np.isfinite(xe).any()        # every entry non-finite on both sides, no crash
+    assert not np.isfinite(e.get_P()).any() and not np.isfinite(ref.P).any()
+
+
+def test_heading_landing_exactly_on_360_stays_360():
+    e, d = _pair(2, 5)
+    for eng in (e, d):
+        xs = (eng.get_x() if hasattr(eng, "get_x") else eng.x).copy()
+    x = d.x.copy(); x[2] = 350.0
+    e.set_state(x, d.P, np.arange(1, 3.0)); d.x = x.copy()
+    e.predict([0.5, 10.0]); d.predict([0.5, 10.0])
+    assert d.x[2] == 360.0 and e.get_x()[2] == 360.0
+    z, R = [5.0, 33.0], np.diag([0.05, 165.0])
+    e.correct(z, R, 0); d._correct(z, R, 1)
+    assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
+
+
+def test_capacity_reached_exactly_then_refused():
+    from ekf_slam_amd import Engine, EkfError, _lib as L
+    from oracle import ekf_dense as D
+    e, d = Engine(capacity=3, tile=16), D.EKF_SLAM()
+    R = np.diag([0.02, 10.0])
+    for k in range(3):
+        e.append([0.1, 5.0], R, [1.0 + k, 2.0 - k], k + 1); d.append([0.1, 5.0], R, [1.0 + k, 2.0 - k], k + 1)
+    assert e.N == 3 and rel_err(e.get_P(), d.P) < REL
+    with pytest.raises(EkfError) as ei:
+        e.append([0.1, 5.0], R, [9.0, 9.0], 4)
+    assert ei.value.status == L.EKF_ERR_CAPACITY and e.N == 3
+    e.correct([2.0, 40.0], R, 2); d._correct([2.0, 40.0], R, 3)            # still usable at capacity
+    assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
