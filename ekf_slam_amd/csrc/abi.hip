@@ -105,6 +105,12 @@ struct ekf_handle {
     AssocDecision *h_decision_dev = nullptr;   // device-side address of the mapped h_decision (the association kernel writes it)
     int *d_ticket = nullptr;                   // k_associate's last-workgroup ticket
     int32_t assoc_seq = 0;
+    // cfg.device_assoc == 2: measure() dispatches on the host mirror's decision while k_associate runs for every observation in
+    // the stream; its decisions land in this mapped ring and are VERIFIED against the host's before measure() returns
+    static constexpr int kSpecRing = 64;
+    AssocDecision *h_spec = nullptr, *h_spec_dev = nullptr;
+    struct Spec { int32_t seq, is_new; int64_t idx; };
+    std::vector<Spec> spec;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
     // sharded correction: exchange slabs (own allocations, or caller-provided device buffers)
@@ -531,8 +537,9 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     return finish_step(h);
 }
 
-int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
-                     double *pos_cost, double *sig_cost) {
+// queue k_associate for observation z on the handle's stream; the decision goes to the device copy and, if host_slot != nullptr,
+// to that mapped host slot (sequence number `seq` written last)
+int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocDecision *host_slot_dev, int32_t seq) {
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
     REQUIRE(h, h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
             "associate: w_pos != 0 needs the diagonal blocks of other shards (not supported on a sharded handle)");
@@ -545,26 +552,53 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
     a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
     a.N = h->N; a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
-    const int32_t seq = ++h->assoc_seq == 0 ? ++h->assoc_seq : h->assoc_seq;       // never 0: that is the mapped copy's initial value
-    {
-        TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
-        HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_ticket, h->d_decision,
-                                   h->h_decision_dev, seq, h->storage, h->stream));
+    TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
+    HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_ticket, h->d_decision, host_slot_dev, seq,
+                               h->storage, h->stream));
+    return EKF_OK;
+}
+
+inline int32_t next_assoc_seq(ekf_handle *h) { return ++h->assoc_seq == 0 ? ++h->assoc_seq : h->assoc_seq; }   // never 0: a slot's initial value
+
+// wait (bounded poll, then stream synchronisation) until the mapped slot carries sequence number seq
+bool wait_mapped_seq(volatile AssocDecision *slot, int32_t seq) {
+    for (int spin = 0; spin < 2000000; ++spin) {
+        if (slot->seq == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
+        __builtin_ia32_pause();
     }
+    return false;
+}
+
+// cfg.device_assoc == 2: every decision the device has produced since the last call must equal the host mirror's
+int32_t verify_speculated(ekf_handle *h) {
+    if (h->spec.empty()) return EKF_OK;
+    const size_t n = h->spec.size();
+    volatile AssocDecision *last = h->h_spec + ((n - 1) % ekf_handle::kSpecRing);
+    if (!wait_mapped_seq(last, h->spec[n - 1].seq)) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));            // the kernels have retired: the mapped writes are complete
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    int32_t rc = EKF_OK;
+    for (size_t q = 0; q < n && !rc; ++q) {
+        const volatile AssocDecision *d = h->h_spec + (q % ekf_handle::kSpecRing);
+        if (d->seq != h->spec[q].seq || d->is_new != h->spec[q].is_new || d->index != h->spec[q].idx)
+            rc = fail(h, EKF_ERR_STATE, "measure: the device association disagrees with the host mirror of the signatures");
+    }
+    h->spec.clear();
+    return rc;
+}
+
+int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
+                     double *pos_cost, double *sig_cost) {
+    const int32_t seq = next_assoc_seq(h);
+    int32_t rc = launch_assoc(h, z, R, h->h_decision_dev, seq);
+    if (rc) return rc;
     if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
     if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    bool have = false;
-    if (h->h_decision_dev && !pos_cost && !sig_cost) {
-        // measure()'s path: the kernel writes the decision into mapped host memory (sequence number last, behind a system-scope
-        // fence); polling for it costs ~2 us after the kernel retires, a device->host copy + stream synchronisation ~15 us.
-        // Bounded: after ~2 ms the ordinary path below takes over.
-        volatile AssocDecision *hd = h->h_decision;
-        for (int spin = 0; spin < 2000000; ++spin) {
-            if (hd->seq == seq) { have = true; break; }
-            __builtin_ia32_pause();
-        }
-        if (have) __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
+    // measure()'s path: the kernel writes the decision into mapped host memory (sequence number last, behind a system-scope
+    // fence); polling for it costs ~2 us after the kernel retires, a device->host copy + stream synchronisation ~15 us.
+    // Bounded: after ~2 ms the ordinary path below takes over.
+    const bool have = h->h_decision_dev && !pos_cost && !sig_cost && wait_mapped_seq(h->h_decision, seq);
     if (!have) {
         HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -774,6 +808,13 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         void *dp = nullptr;
         if (poll && hipHostGetDevicePointer(&dp, h->h_decision, 0) == hipSuccess) h->h_decision_dev = (AssocDecision *)dp;
     }
+    if (cfg->device_assoc == 2) {
+        HIPCHK(h, hipHostMalloc((void **)&h->h_spec, sizeof(AssocDecision) * ekf_handle::kSpecRing, hipHostMallocMapped));
+        memset(h->h_spec, 0, sizeof(AssocDecision) * ekf_handle::kSpecRing);
+        void *dp = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0));
+        h->h_spec_dev = (AssocDecision *)dp;
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
 
     // x = [0 0 0]; P = 0.1*eye(3)   (EKF_SLAM.m:28-31, EKF_SLAM_UC.m:29-32)
@@ -800,6 +841,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);
+    if (h->h_spec) hipHostFree(h->h_spec);
     if (h->h_small) hipHostFree(h->h_small);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -939,27 +981,37 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
             int32_t is_new = 0;
             int64_t idx = 0;
             static const bool force_dev = [] { const char *v = getenv("EKF_FORCE_DEVICE_ASSOC"); return v && atoi(v) != 0; }();
-            if (h->cfg.w_pos == 0.0 && !force_dev && !h->cfg.device_assoc) {
+            if (h->cfg.w_pos == 0.0 && !force_dev && h->cfg.device_assoc != 1) {
                 // The reference's decision is a pure function of z(3) and s: the Mahalanobis position cost it also
                 // evaluates is discarded (Correspondence.m:74-75).  With w_pos == 0 measure() therefore decides from
                 // the host mirror of s -- same arithmetic as k_associate, no launch, no device->host sync.
                 // ekf_associate() always runs the full device computation.
                 associate_signature_only(h, z[2], &is_new, &idx);
+                if (h->cfg.device_assoc == 2 && h->h_spec_dev) {
+                    // ... and with device_assoc == 2 the device evaluates the association all the same (per-landmark phi_k,
+                    // Mahalanobis and signature cost, arg-min), queued behind the previous row's kernels; the host does not wait
+                    // for it but checks every decision against its own before measure() returns
+                    if ((int)h->spec.size() == ekf_handle::kSpecRing) { rc = verify_speculated(h); if (rc) return rc; }
+                    const int32_t seq = next_assoc_seq(h);
+                    rc = launch_assoc(h, z, R, h->h_spec_dev + (h->spec.size() % ekf_handle::kSpecRing), seq);
+                    if (rc) { verify_speculated(h); return rc; }
+                    h->spec.push_back({ seq, is_new, idx });
+                }
             } else {
                 rc = do_associate(h, z, R, &is_new, &idx, nullptr, nullptr);   // EKF_SLAM_UC.m:119
                 if (rc) return rc;
             }
             if (is_new) {                                                  // EKF_SLAM_UC.m:121-123
                 rc = lookup_loc(h, lm_index, lm_loc, L, false, (double)(idx + 1), loc);
-                if (rc) return rc;
+                if (rc) { verify_speculated(h); return rc; }
                 rc = do_append(h, u, R, loc, (double)(idx + 1));
             } else {
                 rc = do_correct(h, z, R, idx);
             }
         }
-        if (rc) return rc;
+        if (rc) { verify_speculated(h); return rc; }
     }
-    return EKF_OK;
+    return verify_speculated(h);
 }
 
 int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {

@@ -35,7 +35,7 @@ class Engine:
         cfg.storage = L.EKF_STORE_F64 if storage == "f64" else L.EKF_STORE_F32
         cfg.device, cfg.rank, cfg.world, cfg.batch = int(device), int(rank), int(world), int(batch)
         cfg.async_flush = 1 if async_flush else 0
-        cfg.device_assoc = 1 if device_assoc else 0
+        cfg.device_assoc = int(device_assoc)      # False / 0: host mirror, True / 1: device, waited for, 2: device, verified afterwards
         for k, v in overrides.items():
             if k == "Rc":
                 cfg.Rc[0], cfg.Rc[1] = float(v[0]), float(v[1])

@@ -75,12 +75,17 @@ typedef struct ekf_config {
                                     beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
                                     async_flush = 0.  The second stream is confined to a CU mask that leaves 32 CUs
                                     (EKF_ASYNC_RESERVE_CUS) to the corrections. */
-    int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure: 1 = every observation runs the association kernels on the device
-                                    (per-landmark phi_k, Mahalanobis and signature cost, arg-min: Correspondence.m:49-87 as
-                                    the reference evaluates it).  0 (default) = when w_pos == 0 the decision is taken from
-                                    the host mirror of s -- the reference's live likelihood is signature-only
-                                    (Correspondence.m:75), so the result is the same, without a launch and a device->host
-                                    sync per observation.  ekf_associate() always runs on the device. */
+    int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure, when w_pos == 0 (the reference's live likelihood is signature-only,
+                                    Correspondence.m:75, so the decision is a function of z(3) and s alone):
+                                    0 (default): the decision is taken from the host mirror of s -- no launch, no sync;
+                                    1: every observation runs the association kernel on the device (per-landmark phi_k,
+                                       Mahalanobis and signature cost, arg-min: Correspondence.m:49-87 as the reference
+                                       evaluates it) and the host WAITS for its decision;
+                                    2: the kernel runs for every observation all the same, but the host dispatches on its
+                                       mirror's decision without waiting and VERIFIES every device decision against it before
+                                       ekf_measure returns (EKF_ERR_STATE on a mismatch).
+                                    With w_pos != 0 the device decides (and is waited for) whatever this says;
+                                    ekf_associate() always runs on the device. */
     int32_t reserved[5];
 } ekf_config;
 

@@ -4,7 +4,8 @@ a warm-up sweep appends all 1 000 landmarks through measure(), then SLAM iterati
 nearest landmarks).  Run twice: with the association decided per observation by the device kernels (k_associate: per-landmark
 phi_k, Mahalanobis and signature cost, arg-min -- what the reference evaluates, Correspondence.m:49-87) and with the
 host-mirror shortcut that is legitimate because the reference's live likelihood is signature-only (Correspondence.m:75); both
-must give the same state bit for bit."""
+must give the same state bit for bit -- and so must the third mode (cfg.device_assoc = 2), in which the kernel runs for every
+observation but the host dispatches on its mirror's decision and verifies the device's afterwards."""
 import numpy as np
 import pytest
 
@@ -23,7 +24,8 @@ def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     from oracle.ekf_structured import StructuredEKF
     _, run = make_run(N, 20260102, 2 + ITERS, policy="nearest", m=M)
-    gpus = {"device": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=True), "host": EKF_SLAM_UC(capacity=N, batch=8)}
+    gpus = {"device": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=True), "host": EKF_SLAM_UC(capacity=N, batch=8),
+            "verified": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=2)}     # device kernels in the stream, checked after dispatch
     lms = {k: Landmark('SYNTHETIC') for k in gpus}
     ref, lr = StructuredEKF(N, "uc"), SyntheticLandmark()
     for t, (u, scan) in enumerate(run):
@@ -38,8 +40,9 @@ def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
     ex, eP = rel_err(xd, ref.x), rel_err(Pd, ref.P)
     print("1k UC: %d iterations x %d observations, rel err x %.2e P %.2e" % (ITERS, M, ex, eP))
     assert ex < REL and eP < REL
-    np.testing.assert_array_equal(gpus["host"].x, xd)
-    np.testing.assert_array_equal(gpus["host"].P, Pd)
+    for k in ("host", "verified"):
+        np.testing.assert_array_equal(gpus[k].x, xd)
+        np.testing.assert_array_equal(gpus[k].P, Pd)
     np.testing.assert_array_equal(gpus["device"].s, ref.s)
     # the device association agrees with the oracle's, costs included, on the final state (pending-free and with pending pairs)
     z = np.asarray(gpus["device"].observed[0], dtype=np.float64)
