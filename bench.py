@@ -304,6 +304,11 @@ def main():
                                    "effective_GBps", "roofline", "state_finite")}
         out["note"] = note
         out["state_digest"] = [float(v) for v in leg["digest"]]
+        if leg["steps"] + leg["warmup"] == head["steps"] + head["warmup"]:
+            # the same update-steps as the as-written leg: the digest kernel adds in a fixed order, so on one GPU equal
+            # states give bit-equal digests (several GPUs: the cross-rank sum is the all-reduce's, equal to rounding)
+            out["digest_equals_as_written_leg"] = bool(np.array_equal(leg["digest"], head["digest"]))
+            out["x_equals_as_written_leg"] = bool(np.array_equal(leg["x_end"], head["x_end"]))
         return out
 
     head = run_leg(1, args.steps, args.warmup)

@@ -787,7 +787,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->d_ticket, 1));
     HIPCHK(h, dalloc(h, &h->d_pos_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_sig_cost, (size_t)h->cap));
-    HIPCHK(h, dalloc(h, &h->d_digest, 4));
+    HIPCHK(h, dalloc(h, &h->d_digest, kDigestDoubles));
     {
         const char *fs = getenv("EKF_FORCE_SHARDED");
         h->sharded = world > 1 || (fs && atoi(fs) != 0);

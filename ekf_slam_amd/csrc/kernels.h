@@ -120,6 +120,9 @@ hipError_t launch_get_diag_blocks(const DevState &st, int cur, int64_t N, double
 // P = diag(d) + U U' (d: n, U: n x k column-major, device)
 hipError_t launch_lowrank(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, const double *d,
                           const double *U, int64_t k, int storage, hipStream_t s);
-// out[3] (device, zeroed by the callee): trace, sum and sum of squares over the lower triangle
+// out (device, kDigestDoubles doubles; [0..2] = trace, sum and sum of squares over the lower triangle, then a ticket and one
+// slot of partial sums per workgroup, added in a fixed order: equal states give bit-equal digests)
+constexpr int kDigestGrid = 2048;
+constexpr int kDigestDoubles = 4 + 3 * kDigestGrid;
 hipError_t launch_digest(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, double *out,
                          int storage, hipStream_t s);

@@ -1427,7 +1427,26 @@ __global__ __launch_bounds__(kBlock) void k_digest(DevState st, int cur, int64_t
             }
     }
     tr = block_sum(tr, sh); sm = block_sum(sm, sh); sq = block_sum(sq, sh);
-    if (threadIdx.x == 0) { atomicAdd(out + 0, tr); atomicAdd(out + 1, sm); atomicAdd(out + 2, sq); }
+    // Deterministic across runs: every workgroup leaves its partial sums in its own slot; the workgroup that takes the last
+    // ticket adds the slots in a fixed order (no floating-point atomics, so equal states give equal digests bit for bit).
+    double *part = out + 4;
+    int *ticket = (int *)(out + 3);
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        part[3 * blockIdx.x + 0] = tr; part[3 * blockIdx.x + 1] = sm; part[3 * blockIdx.x + 2] = sq;
+        __threadfence();
+        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int g = threadIdx.x; g < (int)gridDim.x; g += kBlock) {
+        a += __builtin_nontemporal_load(part + 3 * g); b += __builtin_nontemporal_load(part + 3 * g + 1);
+        c += __builtin_nontemporal_load(part + 3 * g + 2);
+    }
+    a = block_sum(a, sh); b = block_sum(b, sh); c = block_sum(c, sh);
+    if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -1921,9 +1940,9 @@ hipError_t launch_lowrank(const DevState &st, int cur, int64_t n_mm, const int2 
 
 hipError_t launch_digest(const DevState &st, int cur, int64_t n_mm, const int2 *work, int64_t nwork, double *out,
                          int storage, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(out, 0, 3 * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(double), s);      // sums + the ticket; partial slots follow (kDigestSlots)
     if (e != hipSuccess) return e;
-    int64_t grid = nwork < 2048 ? nwork : 2048;
+    int64_t grid = nwork < kDigestGrid ? nwork : kDigestGrid;
     if (grid < 1) grid = 1;
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL(k_digest<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, cur, n_mm, work, nwork, out),
