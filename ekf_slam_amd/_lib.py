@@ -52,6 +52,8 @@ SIGNATURES = {
     "ekf_append": (_i32, [_vp, _dp, _dp, _dp, _d]),
     "ekf_correct": (_i32, [_vp, _dp, _dp, _i64]),
     "ekf_associate": (_i32, [_vp, _dp, _dp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), _dp, _dp]),
+    "ekf_associate_begin": (_i32, [_vp, _dp, _dp, _i32]),
+    "ekf_associate_finish": (_i32, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64), _dp, _dp]),
     "ekf_measure": (_i32, [_vp, _dp, _i64, _dp, _dp, _dp, _i64]),
     "ekf_comm_unique_id": (_i32, [ctypes.c_char_p]),
     "ekf_comm_init": (_i32, [_vp, ctypes.c_char_p]),

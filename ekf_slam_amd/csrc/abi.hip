@@ -117,9 +117,11 @@ struct ekf_handle {
     bool sharded = false;          // world > 1, or forced (EKF_FORCE_SHARDED=1) to exercise the path on one GPU
     double *own_send = nullptr, *own_recv = nullptr, *send = nullptr, *recv = nullptr;
     int64_t slab_cap = 0;          // doubles per shard slab at capacity
+    int64_t xchg_cap = 0;          // doubles of the send area (the receive area holds world times as many)
     int64_t slab = 0;              // doubles per shard slab of the pending correction
     bool pending = false;          // an exchange is between begin and finish ...
-    int pending_kind = 0;          // ... 1: one correction's row-panel, 2: a prefetch of several base row-panels
+    bool assoc_costs = false;      // the pending association's exchange carries the position costs too
+    int pending_kind = 0;          // ... 1: one correction's row-panel, 2: a prefetch of several base row-panels, 3: association candidates
     int64_t x_count = 0;           // doubles per shard of the pending exchange
     CorrectArgs pending_args;
     // prefetched BASE row-panels (ekf_prefetch_rows): valid until the tiles change (flush) or the map grows
@@ -539,25 +541,6 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
 
 // queue k_associate for observation z on the handle's stream; the decision goes to the device copy and, if host_slot != nullptr,
 // to that mapped host slot (sequence number `seq` written last)
-int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocDecision *host_slot_dev, int32_t seq) {
-    REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
-    REQUIRE(h, h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
-            "associate: w_pos != 0 needs the diagonal blocks of other shards (not supported on a sharded handle)");
-    {
-        const int32_t rcp = materialize_predict(h);
-        if (rcp) return rcp;
-    }
-    AssocArgs a;
-    a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
-    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
-    a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
-    a.N = h->N; a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
-    TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
-    HIPCHK(h, launch_associate(h->st, a, h->d_pos_cost, h->d_sig_cost, h->d_partial, h->d_ticket, h->d_decision, host_slot_dev, seq,
-                               h->storage, h->stream));
-    return EKF_OK;
-}
-
 inline int32_t next_assoc_seq(ekf_handle *h) { return ++h->assoc_seq == 0 ? ++h->assoc_seq : h->assoc_seq; }   // never 0: a slot's initial value
 
 // wait (bounded poll, then stream synchronisation) until the mapped slot carries sequence number seq
@@ -567,6 +550,62 @@ bool wait_mapped_seq(volatile AssocDecision *slot, int32_t seq) {
         __builtin_ia32_pause();
     }
     return false;
+}
+
+// exchange == false: the decision of this launch is final (unsharded, or sharded with the signature-only likelihood, which every
+// shard evaluates identically from replicated data); exchange == true (sharded): this shard nominates among the landmarks whose
+// diagonal block it holds and leaves its candidate -- and, want_costs, their position costs -- in the send area
+int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocDecision *host_slot_dev, int32_t seq,
+                     bool exchange = false, bool want_costs = false) {
+    REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
+    REQUIRE(h, exchange || h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
+            "associate: with w_pos != 0 a sharded handle needs the candidates of the other shards (ekf_comm_init, or "
+            "ekf_associate_begin / your all-gather / ekf_associate_finish)");
+    {
+        const int32_t rcp = materialize_predict(h);
+        if (rcp) return rcp;
+    }
+    AssocArgs a;
+    a.z0 = z[0]; a.z1 = z[1]; a.z2 = z[2];
+    colmajor2(R, a.R00, a.R01, a.R10, a.R11);
+    a.s_cost = h->cfg.s_cost; a.s_thresh = h->cfg.s_thresh; a.w_pos = h->cfg.w_pos;
+    a.N = h->N; a.cur = h->cur; a.npend = h->npend; a.pstart = h->pstart;
+    a.own_only = exchange ? 1 : 0;
+    TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
+    HIPCHK(h, launch_associate(h->st, a, exchange ? (want_costs ? h->send + 4 : nullptr) : h->d_pos_cost, h->d_sig_cost,
+                               h->d_partial, h->d_ticket, h->d_decision, exchange ? nullptr : host_slot_dev, seq,
+                               exchange ? h->send : nullptr, h->storage, h->stream));
+    return EKF_OK;
+}
+
+// sharded association, first half: candidates (+ position costs) into the send area; the exchange moves x_count doubles
+int32_t assoc_begin(ekf_handle *h, const double z[3], const double R[4], bool want_costs) {
+    REQUIRE(h, !h->pending, EKF_ERR_STATE, "associate_begin: an exchange is already pending");
+    const int32_t rc = launch_assoc(h, z, R, nullptr, 0, /*exchange*/ true, want_costs);
+    if (rc) return rc;
+    h->pending = true; h->pending_kind = 3; h->x_count = 4 + (want_costs ? h->N : 0);
+    h->assoc_costs = want_costs;
+    return EKF_OK;
+}
+
+// second half: every shard takes the same arg-min over the gathered candidates; then as do_associate
+int32_t assoc_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pos_cost, double *sig_cost) {
+    REQUIRE(h, h->pending && h->pending_kind == 3, EKF_ERR_STATE, "associate_finish: no association pending");
+    REQUIRE(h, !pos_cost || h->assoc_costs, EKF_ERR_STATE, "associate_finish: position costs were not requested at begin");
+    h->pending = false; h->pending_kind = 0;
+    const int32_t seq = next_assoc_seq(h);
+    HIPCHK(h, launch_assoc_merge(h->st, h->recv, h->cfg.world, h->x_count, h->N, h->assoc_costs, h->d_pos_cost, h->d_decision,
+                                 h->h_decision_dev, seq, h->stream));
+    if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    const bool have = h->h_decision_dev && !pos_cost && !sig_cost && wait_mapped_seq(h->h_decision, seq);
+    if (!have) {
+        HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    *is_new = h->h_decision->is_new;
+    *idx = h->h_decision->index;
+    return EKF_OK;
 }
 
 // cfg.device_assoc == 2: every decision the device has produced since the last call must equal the host mirror's
@@ -590,6 +629,18 @@ int32_t verify_speculated(ekf_handle *h) {
 
 int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
                      double *pos_cost, double *sig_cost) {
+    if (h->sharded && (h->cfg.w_pos != 0.0 || pos_cost)) {
+        // the position cost needs every landmark's diagonal block, and those are dealt over the shards: one small all-gather
+        // (SURVEY.md 8e).  The signature-only decision (the reference's, Correspondence.m:75) needs none.
+        REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
+                "associate: position costs on a sharded handle need an exchange -- call ekf_comm_init, or drive "
+                "ekf_associate_begin / your own all-gather / ekf_associate_finish");
+        int32_t rc = assoc_begin(h, z, R, pos_cost != nullptr);
+        if (rc) return rc;
+        rc = exchange_rccl(h);
+        if (rc) { h->pending = false; return rc; }
+        return assoc_finish(h, is_new, idx, pos_cost, sig_cost);
+    }
     const int32_t seq = next_assoc_seq(h);
     int32_t rc = launch_assoc(h, z, R, h->h_decision_dev, seq);
     if (rc) return rc;
@@ -794,8 +845,10 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         if (h->sharded) {
             h->slab_cap = slab_for(h, 2 * h->cap);
             const size_t rows = (size_t)(cfg->batch < 1 ? 1 : cfg->batch);     // a prefetch carries up to `batch` row-panels
-            HIPCHK(h, dalloc(h, &h->own_send, (size_t)h->slab_cap * rows));
-            HIPCHK(h, dalloc(h, &h->own_recv, (size_t)h->slab_cap * rows * world));
+            // ... and an association's exchange a candidate + one position cost per landmark
+            h->xchg_cap = std::max<int64_t>(h->slab_cap * (int64_t)rows, 4 + h->cap);
+            HIPCHK(h, dalloc(h, &h->own_send, (size_t)h->xchg_cap));
+            HIPCHK(h, dalloc(h, &h->own_recv, (size_t)h->xchg_cap * world));
             HIPCHK(h, dalloc(h, &h->pf_store, (size_t)h->slab_cap * rows * world));
             h->send = h->own_send;
             h->recv = h->own_recv;
@@ -1027,6 +1080,19 @@ int32_t ekf_correct_finish(ekf_handle *h) {
     return rc ? rc : correct_finish(h);
 }
 
+int32_t ekf_associate_begin(ekf_handle *h, const double z[3], const double R[4], int32_t want_costs) {
+    if (!h || !z || !R) return fail(h, EKF_ERR_INVALID_ARG, "associate_begin: null argument");
+    REQUIRE(h, h->sharded, EKF_ERR_STATE, "associate_begin: handle is not sharded (use ekf_associate)");
+    int32_t rc = use_device(h);
+    return rc ? rc : assoc_begin(h, z, R, want_costs != 0);
+}
+
+int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pos_cost, double *sig_cost) {
+    if (!h || !is_new || !idx) return fail(h, EKF_ERR_INVALID_ARG, "associate_finish: null argument");
+    int32_t rc = use_device(h);
+    return rc ? rc : assoc_finish(h, is_new, idx, pos_cost, sig_cost);
+}
+
 int32_t ekf_prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
     if (!h || !idx) return fail(h, EKF_ERR_INVALID_ARG, "prefetch_begin: null argument");
     REQUIRE(h, h->sharded, EKF_ERR_STATE, "prefetch_begin: handle is not sharded");
@@ -1058,7 +1124,7 @@ int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *coun
     if (send) *send = h->send;
     if (recv) *recv = h->recv;
     if (count) *count = h->pending ? h->x_count : h->slab;
-    if (count_capacity) *count_capacity = h->slab_cap * h->batch;
+    if (count_capacity) *count_capacity = h->xchg_cap;
     return EKF_OK;
 }
 

@@ -60,6 +60,7 @@ struct AssocArgs {
     int32_t cur;
     int32_t npend;
     int32_t pstart;
+    int32_t own_only;         // sharded association with an exchange: nominate only landmarks whose diagonal block this shard holds
 };
 
 struct AssocDecision {        // written by the device, read back by the host
@@ -109,7 +110,12 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 // field last, behind a system-scope fence (the host polls for seq == `seq`)
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
-                            int storage, hipStream_t s);
+                            double *cand, int storage, hipStream_t s);
+// cand (nullptr or 4 device doubles): this shard's candidate {likelihood, index or -1, 0, 0} for the all-gather of a sharded
+// association; launch_assoc_merge takes the arg-min over the `world` gathered contributions of `count` doubles each (candidate,
+// then -- want_costs -- N position costs) and writes the decision like launch_associate does
+hipError_t launch_assoc_merge(const DevState &st, const double *recv, int world, int64_t count, int64_t N, bool want_costs,
+                              double *pos_cost, AssocDecision *decision, AssocDecision *host_decision, int seq, hipStream_t s);
 // dense (column-major, n x n, device) <-> tiled
 hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s);
 hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s);

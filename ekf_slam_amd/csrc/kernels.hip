@@ -1181,7 +1181,7 @@ template <typename TS>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
                                                            AssocDecision *partial, int *ticket, AssocDecision *__restrict__ decision,
-                                                           AssocDecision *host_decision, int seq) {
+                                                           AssocDecision *host_decision, int seq, double *__restrict__ cand) {
     __shared__ double sh_ll[kAssocBlock];
     __shared__ int64_t sh_ix[kAssocBlock];
     const int tid = threadIdx.x;
@@ -1239,7 +1239,9 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         if (pos_cost) pos_cost[k] = pc;
         if (sig_cost) sig_cost[k] = sc;
         const double like = (a.w_pos != 0.0) ? (a.w_pos * pc + sc) : sc;                                      // :74-75
-        if (like <= a.s_thresh) { ll = like; ix = k; }                                                       // :78
+        // a.own_only (sharded association with an exchange): a shard only nominates landmarks whose diagonal
+        // block it holds; the candidates of all shards meet in k_assoc_merge
+        if (like <= a.s_thresh && (have_diag || !a.own_only)) { ll = like; ix = k; }                         // :78
     }
     sh_ll[tid] = ll; sh_ix[tid] = ix;
     __syncthreads();
@@ -1283,8 +1285,45 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         d.seq = seq;
         *decision = d;
         *ticket = 0;                                  // ready for the next launch (stream order)
+        if (cand) { cand[0] = sh_ll[0]; cand[1] = found ? (double)sh_ix[0] : -1.0; cand[2] = 0.0; cand[3] = 0.0; }
         if (host_decision) {
             // mapped host memory: payload first, then -- behind a system-scope fence -- the sequence number the host polls for
+            volatile AssocDecision *hd = host_decision;
+            hd->index = d.index; hd->is_new = d.is_new; hd->min_ll = d.min_ll;
+            __threadfence_system();
+            hd->seq = seq;
+        }
+    }
+}
+
+// Sharded association, after the all-gather: contribution r of `recv` holds shard r's candidate {likelihood, 0-based index or
+// -1, 0, 0} and, if costs travel too, its position costs (4 + k; NaN where shard r does not hold landmark k's diagonal block).
+// Every shard takes the same strict arg-min over the candidates (Correspondence.m:78-85: lowest likelihood, lowest index on
+// ties -- what the unsharded kernel's reduction does) and assembles pos_cost from each landmark's owner.
+__global__ __launch_bounds__(kBlock) void k_assoc_merge(TileMap tm, const double *__restrict__ recv, int world, int64_t count,
+                                                        int64_t N, int want_costs, double *__restrict__ pos_cost,
+                                                        AssocDecision *__restrict__ decision, AssocDecision *host_decision,
+                                                        int seq) {
+    if (want_costs)
+        for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < N; k += (int64_t)gridDim.x * kBlock) {
+            const int64_t I = (2 * k) >> tm.shift;
+            pos_cost[k] = recv[(int64_t)tm.owner(I, I) * count + 4 + k];
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double ll = INFINITY;
+        int64_t ix = INT64_MAX;
+        for (int r = 0; r < world; ++r) {
+            const double cl = recv[(int64_t)r * count], ci = recv[(int64_t)r * count + 1];
+            if (ci >= 0.0 && assoc_better(cl, (int64_t)ci, ll, ix)) { ll = cl; ix = (int64_t)ci; }
+        }
+        const bool found = ix != INT64_MAX;
+        AssocDecision d;
+        d.is_new = found ? 0 : 1;
+        d.index = found ? ix : N;
+        d.min_ll = ll;
+        d.seq = seq;
+        *decision = d;
+        if (host_decision) {
             volatile AssocDecision *hd = host_decision;
             hd->index = d.index; hd->is_new = d.is_new; hd->min_ll = d.min_ll;
             __threadfence_system();
@@ -1878,13 +1917,22 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
-                            int storage, hipStream_t s) {
+                            double *cand, int storage, hipStream_t s) {
     const int64_t grid = cdiv(a.N > 0 ? a.N : 1, kAssocBlock);
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_decision, seq),
+                           decision, host_decision, seq, cand),
         hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_decision, seq));
+                           decision, host_decision, seq, cand));
+    return hipGetLastError();
+}
+
+hipError_t launch_assoc_merge(const DevState &st, const double *recv, int world, int64_t count, int64_t N, bool want_costs,
+                              double *pos_cost, AssocDecision *decision, AssocDecision *host_decision, int seq, hipStream_t s) {
+    int64_t grid = want_costs ? cdiv(N > 0 ? N : 1, kBlock) : 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_assoc_merge, dim3((unsigned)grid), dim3(kBlock), 0, s, st.tm, recv, world, count, N, want_costs ? 1 : 0,
+                       pos_cost, decision, host_decision, seq);
     return hipGetLastError();
 }
 

@@ -163,6 +163,11 @@ class Engine:
         self._check(self.lib.ekf_comm_init(self.h, bytes(comm_id_bytes)))
 
     def associate(self, z, R, want_costs=False):
+        if self._host_exchange is not None and (want_costs or self.cfg.w_pos != 0.0):
+            # sharded, all-gather done by the host: the position cost needs the other shards' diagonal blocks
+            self.associate_begin(z, R, want_costs)
+            self._host_exchange(self)
+            return self.associate_finish(want_costs)
         is_new, idx = ctypes.c_int32(), ctypes.c_int64()
         N = self.N
         pc = np.zeros(max(N, 1)) if want_costs else None
@@ -170,6 +175,22 @@ class Engine:
         self._check(self.lib.ekf_associate(self.h, _p(_vec(z, 3)), _p(_colmajor(R).reshape(-1, order="F")),
                                            ctypes.byref(is_new), ctypes.byref(idx),
                                            _p(pc) if want_costs else None, _p(sc) if want_costs else None))
+        if want_costs:
+            return bool(is_new.value), int(idx.value), pc[:N], sc[:N]
+        return bool(is_new.value), int(idx.value)
+
+    # ---- sharded association with position costs, split around the caller's all-gather (include/ekfslam.h) ----
+    def associate_begin(self, z, R, want_costs=False):
+        self._check(self.lib.ekf_associate_begin(self.h, _p(_vec(z, 3)), _p(_colmajor(R).reshape(-1, order="F")),
+                                                 1 if want_costs else 0))
+
+    def associate_finish(self, want_costs=False):
+        is_new, idx = ctypes.c_int32(), ctypes.c_int64()
+        N = self.N
+        pc = np.zeros(max(N, 1)) if want_costs else None
+        sc = np.zeros(max(N, 1)) if want_costs else None
+        self._check(self.lib.ekf_associate_finish(self.h, ctypes.byref(is_new), ctypes.byref(idx),
+                                                  _p(pc) if want_costs else None, _p(sc) if want_costs else None))
         if want_costs:
             return bool(is_new.value), int(idx.value), pc[:N], sc[:N]
         return bool(is_new.value), int(idx.value)

@@ -158,10 +158,28 @@ class ShardGroup:
         if rc:
             raise L.EkfError(rc, e.lib.ekf_last_error(e.h).decode())
 
-    def associate(self, z, R):
-        res = [e.associate(z, R) for e in self.shards]
-        assert all(r == res[0] for r in res), "shards disagree on the association"
+    def associate(self, z, R, want_costs=False):
+        """estimateCorrespondence on the group.  Signature-only likelihood and no costs asked for: every shard decides alone
+        from replicated data.  Otherwise (w_pos != 0, or the cost vectors): each shard scores the landmarks whose diagonal
+        block it holds, one exchange of the candidates (+ position costs), the same arg-min on every shard."""
+        if want_costs or self.shards[0].cfg.w_pos != 0.0:
+            for e in self.shards:
+                e.associate_begin(z, R, want_costs)
+            rc = self.lib.ekf_exchange_local(self._harr, self.world)
+            if rc:
+                raise L.EkfError(rc, self.lib.ekf_last_error(self.shards[0].h).decode())
+            res = [e.associate_finish(want_costs) for e in self.shards]
+        else:
+            res = [e.associate(z, R) for e in self.shards]
+        for r in res[1:]:
+            assert r[:2] == res[0][:2], "shards disagree on the association"
+            for a, b in zip(r[2:], res[0][2:]):
+                np.testing.assert_array_equal(a, b)
         return res[0]
+
+    def set_params(self, **kw):
+        for e in self.shards:
+            e.set_params(**kw)
 
     def set_state(self, x, P, s):
         for e in self.shards:

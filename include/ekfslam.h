@@ -134,6 +134,15 @@ int32_t ekf_correct(ekf_handle *h, const double z[2], const double R[4], int64_t
  * optional N-element outputs (Correspondence.m:69,71), may be NULL. */
 int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
                       double *pos_cost, double *sig_cost);
+/* On a sharded handle (cfg.world > 1) the signature-only decision (w_pos == 0, the reference's live likelihood) is taken
+ * identically by every shard from replicated data.  The position cost needs each landmark's 2x2 diagonal block, and those are
+ * dealt over the shards: with w_pos != 0, or when pos_cost is asked for, every shard scores the landmarks whose diagonal block
+ * it holds, the candidates {likelihood, index} -- and the position costs, if asked for -- travel in ONE all-gather of
+ * 4 (+ N) doubles per shard, and every shard takes the same strict arg-min (lowest likelihood, lowest index on ties: the
+ * decision of the unsharded handle bit for bit).  ekf_associate / ekf_measure run begin + ncclAllGather + finish on a handle with
+ * ekf_comm_init; ekf_associate_begin / _finish bracket the caller's exchange otherwise (ekf_exchange_info, ekf_exchange_local). */
+int32_t ekf_associate_begin(ekf_handle *h, const double z[3], const double R[4], int32_t want_costs);
+int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pos_cost, double *sig_cost);
 
 /* measure(h,laserData,u,landmark_list) AFTER the landmark front-end has run, i.e. the loop
  * EKF_SLAM.m:105-150 / EKF_SLAM_UC.m:107-151 over observed_LL (m x 3 column-major [range, bearing_deg, index]).
@@ -169,7 +178,7 @@ int32_t ekf_prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m);
 int32_t ekf_prefetch_finish(ekf_handle *h);
 /* Device pointers of the exchange: send area (*count doubles valid for the pending begin) and receive area (world
  * contributions of *count doubles, contribution r from shard r); *count_capacity = largest count at capacity
- * (cfg.batch row-panels). */
+ * (cfg.batch row-panels, or an association's candidate + one position cost per landmark, whichever is larger). */
 int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity);
 /* Use caller-owned device buffers (>= count_capacity and world * count_capacity doubles); NULL restores the own ones. */
 int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv);

@@ -81,6 +81,75 @@ def test_shard_group_uc_association(oracle_lib):
     g.close()
 
 
+@pytest.mark.parametrize("world,tile,batch", [(2, 16, 1), (3, 16, 4), (4, 32, 1), (8, 16, 8), (2, 64, 4)])
+def test_shard_group_association_with_position_cost(world, tile, batch, oracle_lib):
+    """with the position cost in the likelihood (w_pos != 0, Correspondence.m:74) every shard scores the landmarks
+    whose 2x2 diagonal block it holds, ONE all-gather carries the candidates (+ the position costs when asked for), and every
+    shard takes the same arg-min: decision and cost vectors equal the unsharded engine's bit for bit (same kernel arithmetic,
+    pending pairs applied on the fly when batch > 1) and the structured oracle's to 1e-6."""
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    from oracle.ekf_structured import StructuredEKF
+    N = 150
+    x, P, s, _, _ = _state(N, 51)
+    kw = dict(mode="uc", capacity=N + 4, tile=tile, batch=batch)
+    g, one, ref = ShardGroup(world, **kw), Engine(**kw), StructuredEKF(N + 4, "uc")
+    for e in (g, one):
+        e.set_params(w_pos=1.0, s_cost=200.0, s_thresh=1e9)
+    ref.w_pos, ref.s_cost, ref.s_thresh = 1.0, 200.0, 1e9
+    g.set_state(x, P, s); one.set_state(x, P, s); ref.set_state(x, P, s)
+    rng = np.random.default_rng(6)
+    for step in range(6):
+        u = [0.1, 3.0]
+        g.predict(u); one.predict(u); ref.predict(u)
+        # an observation of landmark k from the current estimate (+ noise), so that the position cost picks it
+        k = int(rng.integers(0, N))
+        xe = one.get_x()
+        dx, dy = xe[3 + 2 * k] - xe[0], xe[4 + 2 * k] - xe[1]
+        z = [np.hypot(dx, dy) + rng.normal(0, .02), (np.degrees(np.arctan2(dy, dx)) - xe[2]) % 360.0, float(rng.integers(1, N))]
+        R = np.diag([z[0] * .1, max(z[1], 1.0) * 5.0])
+        ng, ig, pcg, scg = g.associate(z, R, want_costs=True)
+        no, io, pco, sco = one.associate(z, R, want_costs=True)
+        nr, ir, pcr, scr = ref.associate(z, R, want_costs=True)
+        assert (ng, ig) == (no, io) == (nr, ir - 1)
+        np.testing.assert_array_equal(pcg, pco)
+        np.testing.assert_array_equal(scg, sco)
+        assert not np.isnan(pcg).any()
+        np.testing.assert_allclose(pcg, pcr, rtol=1e-6)
+        assert g.associate(z, R) == (no, io)                 # without the cost vectors: 4 doubles per shard travel
+        # a correction in between: with batch > 1 it stays pending and the next association patches the blocks on the fly
+        g.correct(z, R, io); one.correct(z, R, io); ref.correct(z, R, io + 1)
+    # nothing passes a tiny threshold: new landmark, default index N (0-based) on every shard
+    for e in (g, one):
+        e.set_params(s_thresh=1e-12)
+    assert g.associate(z, R) == one.associate(z, R) == (True, N)
+    np.testing.assert_array_equal(g.get_x(), one.get_x())
+    g.close(); one.close()
+
+
+def test_position_cost_on_a_shard_needs_an_exchange():
+    """A lone shard cannot score the landmarks whose diagonal blocks live elsewhere: ekf_associate with w_pos != 0 (or asking
+    for the cost vector) on a sharded handle without a communicator is refused, loudly; the signature-only decision is not."""
+    from ekf_slam_amd import EkfError, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 40
+    x, P, s, _, _ = _state(N, 52)
+    g = ShardGroup(2, mode="uc", capacity=N, tile=16)
+    g.set_state(x, P, s)
+    R = np.diag([1.0, 50.0])
+    assert g.shards[1].associate([7.0, 123.0, 5.0], R) == (False, 4)
+    with pytest.raises(EkfError) as ei:
+        g.shards[1].associate([7.0, 123.0, 5.0], R, want_costs=True)
+    assert ei.value.status == L.EKF_ERR_STATE and "exchange" in str(ei.value)
+    g.set_params(w_pos=1.0)
+    with pytest.raises(EkfError) as ei:
+        g.shards[0].associate([7.0, 123.0, 5.0], R)
+    assert ei.value.status == L.EKF_ERR_STATE
+    with pytest.raises(EkfError):                              # finish without begin
+        g.shards[0].associate_finish()
+    g.close()
+
+
 _CHILD = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
@@ -122,6 +191,13 @@ for idx0 in (60, 3, 61):
     e.correct(z, R, idx0); ref.correct(z, R, idx0)
 np.testing.assert_array_equal(e.get_P(), ref.get_P())
 np.testing.assert_array_equal(e.get_x(), ref.get_x())
+# association with the position cost in the likelihood: candidates through the same transport
+for eng in (e, ref):
+    eng.set_params(w_pos=1.0, s_cost=200.0, s_thresh=1e9)
+za, Ra = [9.0, 200.0, 17.0], np.diag([0.9, 1000.0])
+ra, rb = e.associate(za, Ra, want_costs=True), ref.associate(za, Ra, want_costs=True)
+assert ra[:2] == rb[:2] == e.associate(za, Ra)
+np.testing.assert_array_equal(ra[2], rb[2]); np.testing.assert_array_equal(ra[3], rb[3])
 if mode == "rccl":
     # a whole scan through ekf_measure: on a sharded handle with a communicator it fetches the scan's row-panels in
     # one exchange; rows 1..3 correct landmarks 1..3 (known correspondence: idx = row number), row 4 appends
@@ -142,6 +218,30 @@ if mode == "rccl":
     assert e3.N == r2.N == N + 1
     np.testing.assert_array_equal(e3.get_x(), r2.get_x())
     np.testing.assert_array_equal(e3.get_P(), r2.get_P())
+    # unknown correspondence with the position cost in the likelihood, whole scan through ekf_measure on the sharded handle:
+    # every row's association exchanges its candidates (ekf_associate_begin -> ncclAllGather -> finish inside the library)
+    os.environ["EKF_FORCE_SHARDED"] = "1"
+    e4 = Engine(mode="uc", capacity=N + 2, tile=32, batch=4)
+    os.environ["EKF_FORCE_SHARDED"] = "0"
+    r4 = Engine(mode="uc", capacity=N + 2, tile=32, batch=4)
+    raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+    assert L.lib().ekf_comm_unique_id(raw) == 0
+    e4.comm_init(raw.raw)
+    xs = r2.get_x()
+    rows = []
+    for k in (4, 70, 4):
+        dx, dy = x[3 + 2 * k] - x[0], x[4 + 2 * k] - x[1]
+        rows.append([np.hypot(dx, dy), (np.degrees(np.arctan2(dy, dx)) - x[2] - 3.0) %% 360.0, k + 1.0])
+    rows.append([3.0, 10.0, 9999.0])                     # matches nothing within the threshold -> appended
+    obs4 = np.array(rows)
+    for eng in (e4, r4):
+        eng.set_params(w_pos=1.0, s_cost=1e6, s_thresh=50.0)
+        eng.set_state(x, P, s)
+        eng.predict([0.1, 3.0])
+        eng.measure(obs4, [0.1, 3.0], np.array([N + 1.0]), np.array([[1.5, -2.5]]))
+    assert e4.N == r4.N and e4.N in (N, N + 1), (e4.N, r4.N)
+    np.testing.assert_array_equal(e4.get_x(), r4.get_x())
+    np.testing.assert_array_equal(e4.get_P(), r4.get_P())
 print("TRANSPORT", transport)
 """
 
