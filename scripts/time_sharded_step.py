@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""What the SHARDED form of the as-written update-step costs beyond its pass over P, measured on ONE GPU: the handle is forced
+onto the sharded code path (EKF_FORCE_SHARDED=1: k_rowpanel -> all-gather -> k_gather<sharded> -> downdate) with a 1-rank RCCL
+communicator (the all-gather is then a device copy by RCCL's kernel: its launch and kernel cost are in, its xGMI hops are
+not), and timed beside the unsharded handle on the same steps.  Run under `rocprofv3 --kernel-trace --stats` for the
+per-kernel split.
+
+    python scripts/time_sharded_step.py [--landmarks 10000] [--steps 512]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--landmarks", type=int, default=10000)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1)
+    a = ap.parse_args()
+    import bench
+    from ekf_slam_amd import Engine, _lib as L
+    N = a.landmarks
+    w, x, s, d, U = bench.make_state(N, 20260104)
+    steps = bench.make_steps(w, N, 64 + a.steps, [.01, 5.0])
+    out = {"landmarks": N, "steps": a.steps, "batch": a.batch}
+    digests = []
+    for name, forced in (("unsharded", "0"), ("sharded_1rank_rccl", "1")):
+        os.environ["EKF_FORCE_SHARDED"] = forced
+        e = Engine(capacity=N, batch=a.batch)
+        if forced == "1":
+            raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+            assert L.lib().ekf_comm_unique_id(raw) == 0
+            e.comm_init(raw.raw)
+        e.load_lowrank_state(x, s, d, U)
+        warm, timed = e.marshal_steps(steps[:64]), e.marshal_steps(steps[64:])
+        for i in range(warm["m"]):
+            e.step_raw(warm, i)
+        e.flush(); e.sync()
+        t0 = time.perf_counter()
+        for i in range(timed["m"]):
+            e.step_raw(timed, i)
+        e.flush(); e.sync()
+        dt = time.perf_counter() - t0
+        out[name] = {"ms_per_step": round(dt / a.steps * 1e3, 5), "steps_per_s": round(a.steps / dt, 1)}
+        digests.append(e.digest())
+        e.close()
+    out["extra_us_per_step"] = round((out["sharded_1rank_rccl"]["ms_per_step"] - out["unsharded"]["ms_per_step"]) * 1e3, 2)
+    out["same_digest"] = bool(np.array_equal(digests[0], digests[1]))
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
