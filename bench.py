@@ -155,7 +155,7 @@ def main():
                     help="timed steps of the deferred legs (default: 40 batches; always whole batches)")
     ap.add_argument("--async-flush", action="store_true",
                     help="every leg: run each pass over P on a second stream into a second tile store, beside the next gather / "
-                         "exchange (cfg.async_flush; measured on one GPU: 2-6 %% slower, the gather is 1.5 %% of the as-written step)")
+                         "exchange (cfg.async_flush; measured on one GPU: slower at every size, 5-40 %%: profiles/round2_tuning.md sweeps 21, 22)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deferred", action="store_true")
     args = ap.parse_args()

@@ -74,7 +74,9 @@ typedef struct ekf_config {
                                     batch = 1 that is the as-written update-step software-pipelined: the pass of step i
                                     beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
                                     async_flush = 0.  The second stream is confined to a CU mask that leaves 32 CUs
-                                    (EKF_ASYNC_RESERVE_CUS) to the corrections. */
+                                    (EKF_ASYNC_RESERVE_CUS) to the corrections.  Pays when a batch's corrections take
+                                    about as long as its pass; with batch = 1 it has measured slower than the in-place
+                                    pass at every map size on one GPU (two stores defeat the cache). */
     int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure, when w_pos == 0 (the reference's live likelihood is signature-only,
                                     Correspondence.m:75, so the decision is a function of z(3) and s alone):
                                     0 (default): the decision is taken from the host mirror of s -- no launch, no sync;

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--async-flush", action="store_true", help="also time the sharded handle with cfg.async_flush")
     a = ap.parse_args()
     import bench
     from ekf_slam_amd import Engine, _lib as L
@@ -33,9 +34,12 @@ def main():
     steps = bench.make_steps(w, N, 64 + a.steps, [.01, 5.0])
     out = {"landmarks": N, "steps": a.steps, "batch": a.batch}
     digests = []
-    for name, forced in (("unsharded", "0"), ("sharded_1rank_rccl", "1")):
+    legs = [("unsharded", "0", False), ("sharded_1rank_rccl", "1", False)]
+    if a.async_flush:
+        legs += [("unsharded_async", "0", True), ("sharded_1rank_rccl_async", "1", True)]
+    for name, forced, asy in legs:
         os.environ["EKF_FORCE_SHARDED"] = forced
-        e = Engine(capacity=N, batch=a.batch)
+        e = Engine(capacity=N, batch=a.batch, async_flush=asy)
         if forced == "1":
             raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
             assert L.lib().ekf_comm_unique_id(raw) == 0
@@ -54,7 +58,7 @@ def main():
         digests.append(e.digest())
         e.close()
     out["extra_us_per_step"] = round((out["sharded_1rank_rccl"]["ms_per_step"] - out["unsharded"]["ms_per_step"]) * 1e3, 2)
-    out["same_digest"] = bool(np.array_equal(digests[0], digests[1]))
+    out["same_digest"] = all(bool(np.array_equal(digests[0], dg)) for dg in digests[1:])
     print(json.dumps(out), flush=True)
 
 

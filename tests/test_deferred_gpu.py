@@ -97,7 +97,7 @@ def test_deferred_association_costs_see_pending_pairs(oracle_lib):
     assert e.pending() == 5
 
 
-@pytest.mark.parametrize("world,batch,asy", [(2, 4, False), (3, 7, False), (4, 16, False), (2, 4, True), (3, 5, True)])
+@pytest.mark.parametrize("world,batch,asy", [(2, 4, False), (3, 7, False), (4, 16, False), (2, 4, True), (3, 5, True), (2, 1, True), (4, 1, True)])
 def test_deferred_sharded_bitwise(world, batch, asy):
     from ekf_slam_amd import Engine
     from ekf_slam_amd.sharding import ShardGroup
