@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(kBlock) void k_downdate(const TS *__restrict__ tile
     const int cp = tid % kPairsPerRow;       // column pair inside the tile
     const int r0 = tid / kPairsPerRow;       // first row of this lane inside the slab
     const int64_t nitems = nwork * kSlabsPerTile;
-    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+    for (int64_t it0 = blockIdx.x; it0 < nitems; it0 += gridDim.x) {
+        const int64_t it = tm.reverse ? nitems - 1 - it0 : it0;       // alternate passes walk backwards (see k_downdate_w)
         const int64_t w = it / kSlabsPerTile;
         const int slab = (int)(it - w * kSlabsPerTile);
         const int2 ij = work[w];
@@ -1125,9 +1126,15 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
     // kXcd: `work` holds 8 streams of `nwork` tiles each (padded with (-1,-1)); workgroups b and b+8 run on the same
     // XCD (round-robin dispatch -- a speed assumption only), so workgroup b walks stream b % 8 and the XCD's
     // resident workgroups stay inside one or two super-tiles whose K/G slices fit its L2.
+    // tm.reverse: every other pass walks the work list backwards, so that the tiles one pass wrote LAST are the ones the next
+    // pass reads FIRST -- while they are still in the 256 MiB Infinity Cache (it keeps a line while the bytes touched between
+    // two uses of it fit; a store larger than the cache that is always walked in the same direction never meets that).
+    // Results do not depend on the order: every element is updated independently.
     const int64_t nitems = (kXcd ? 8 : 1) * nwork * kSlabsPerTile;
+    const int64_t nv = nwork * kSlabsPerTile;
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t vi = kXcd ? (it >> 3) : it;
+        const int64_t vf = kXcd ? (it >> 3) : it;
+        const int64_t vi = tm.reverse ? nv - 1 - vf : vf;
         const int64_t w = vi / kSlabsPerTile;
         const int slab = (int)(vi - w * kSlabsPerTile);
         const int2 ij = work[kXcd ? (it & 7) * nwork + w : w];
@@ -1614,7 +1621,7 @@ __global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nitems = 8 * nwork * kSlabsPerTile;                 // 8 per-XCD streams (see k_downdate_w)
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t vi = it >> 3;
+        const int64_t vi = tm.reverse ? nwork * kSlabsPerTile - 1 - (it >> 3) : (it >> 3);
         const int64_t w = vi / kSlabsPerTile;
         const int slab = (int)(vi - w * kSlabsPerTile);
         const int2 ij = work[(it & 7) * nwork + w];
@@ -1710,7 +1717,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
     const int lr = lane >> 4, lc = lane & 15;                        // MFMA k / row-group index, MFMA row / column index
     const int64_t nitems = 8 * nwork * kSubsPerTile;                  // 8 per-XCD streams (see k_downdate_w)
     for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t vi = it >> 3;
+        const int64_t vi = tm.reverse ? nwork * kSubsPerTile - 1 - (it >> 3) : (it >> 3);
         const int64_t w = vi / kSubsPerTile;
         const int sub = (int)(vi - w * kSubsPerTile);
         const int2 ij = work[(it & 7) * nwork + w];

@@ -28,6 +28,7 @@ struct TileMap {
     int32_t shift;   // log2(T)
     int32_t world;   // shards
     int32_t rank;    // this shard
+    int32_t reverse = 0;   // pass kernels only: walk the work list backwards (set on alternate passes, abi.hip::next_pass_direction)
 
     // Tile indices are small non-negative numbers: all index arithmetic is 32-bit unsigned (a 64-bit integer division is
     // a ~100-instruction sequence on the GPU and these run in the latency-critical prologue of every gather), and a single
