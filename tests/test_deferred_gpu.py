@@ -248,6 +248,27 @@ def test_mfma_flush_equals_valu_flush_bitwise(tmp_path, storage, tile, batch):
     assert outs[0].tobytes() == outs[1].tobytes()
 
 
+@pytest.mark.parametrize("storage,tile,batch", [("f64", 16, 1), ("f64", 128, 1), ("f64", 128, 6), ("f32", 256, 3), ("f64", 64, 4)])
+def test_pass_direction_does_not_change_a_bit(tmp_path, storage, tile, batch):
+    """Above 256 MiB of tiles every other pass over P walks its work list backwards (the Infinity Cache then serves what the
+    previous pass wrote last).  Every element is updated independently, so the order must not matter: forced on
+    for a small map (EKF_PASS_ALTERNATE=1, read once per process -> child processes), every pass kernel -- generic, one-pair
+    streaming, VALU and MFMA flushes -- against always-forwards, bit for bit.  (At full size the 10 k-landmark tests run with
+    the alternation on by itself.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("P_%s.npy" % flag))
+        env = dict(os.environ, EKF_PASS_ALTERNATE=flag)
+        r = subprocess.run([sys.executable, "-c", _FLUSH_CHILD, root, storage, str(tile), str(batch), out], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all()
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
 def test_marshalled_steps_equal_plain_calls():
     """Engine.marshal_steps / step_raw (pre-marshalled inputs, integer addresses only) is the same sequence of ABI calls as
     predict() + correct() with per-call conversion."""
