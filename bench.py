@@ -168,6 +168,12 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
 
+    # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints a version banner there
+    # when a communicator is created) are sent to stderr for the rest of the run
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     from ekf_slam_amd import Engine
     from ekf_slam_amd import _lib as L
@@ -364,7 +370,7 @@ def main():
                                                      "(ekf_prefetch_rows): one all-gather per batch" % batch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, x, s, d, U, steps[args.warmup:])
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
