@@ -70,7 +70,7 @@ struct AssocDecision {        // written by the device, read back by the host
     double  min_ll;
 };
 
-constexpr int kAssocBlock = 256;
+constexpr int kAssocBlock = 256;       // 4 wavefronts = one per SIMD: the per-landmark solve is a dependent f64 chain (1024 measured slower: 16 wavefronts share one CU's f64 issue)
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
 hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s);

@@ -1184,13 +1184,23 @@ __device__ __forceinline__ bool assoc_better(double la, int64_t ia, double lb, i
     return la < lb || (la == lb && ia < ib);
 }
 
+// arg-min over a wavefront under assoc_better's order (a total order: every lane ends with the same winner)
+__device__ __forceinline__ void wave_argmin(double &ll, int64_t &ix) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ol = __shfl_xor(ll, off);
+        const int64_t oi = __shfl_xor((long long)ix, off);
+        if (assoc_better(ol, oi, ll, ix)) { ll = ol; ix = oi; }
+    }
+}
+
 template <typename TS>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
                                                            AssocDecision *partial, int *ticket, AssocDecision *__restrict__ decision,
                                                            AssocDecision *host_decision, int seq, double *__restrict__ cand) {
-    __shared__ double sh_ll[kAssocBlock];
-    __shared__ int64_t sh_ix[kAssocBlock];
+    __shared__ double sh_ll[kAssocBlock / 64];
+    __shared__ int64_t sh_ix[kAssocBlock / 64];
     const int tid = threadIdx.x;
     const int cur = a.cur;
     const int64_t k = (int64_t)blockIdx.x * kAssocBlock + tid;
@@ -1250,49 +1260,48 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         // block it holds; the candidates of all shards meet in k_assoc_merge
         if (like <= a.s_thresh && (have_diag || !a.own_only)) { ll = like; ix = k; }                         // :78
     }
-    sh_ll[tid] = ll; sh_ix[tid] = ix;
+    // Workgroup arg-min: wavefront butterflies (no barrier), the wavefronts' winners through LDS, one more butterfly in wavefront 0.
+    wave_argmin(ll, ix);
+    if ((tid & 63) == 0) { sh_ll[tid >> 6] = ll; sh_ix[tid >> 6] = ix; }
     __syncthreads();
-    for (int s = kAssocBlock / 2; s > 0; s >>= 1) {
-        if (tid < s && assoc_better(sh_ll[tid + s], sh_ix[tid + s], sh_ll[tid], sh_ix[tid])) {
-            sh_ll[tid] = sh_ll[tid + s]; sh_ix[tid] = sh_ix[tid + s];
+    if (tid < 64) {
+        ll = tid < kAssocBlock / 64 ? sh_ll[tid] : INFINITY;
+        ix = tid < kAssocBlock / 64 ? sh_ix[tid] : INT64_MAX;
+        wave_argmin(ll, ix);
+    }
+    if (gridDim.x > 1) {
+        // several workgroups: the LAST one to get here reduces the per-workgroup minima (one launch instead of two: a finishing
+        // kernel cost a launch and ~5 us in front of a host that waits for the decision)
+        __shared__ int last;
+        if (tid == 0) {
+            partial[blockIdx.x].min_ll = ll; partial[blockIdx.x].index = ix;
+            __threadfence();                                         // the partial is visible before the ticket is drawn
+            last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
         }
         __syncthreads();
-    }
-    // The LAST workgroup to get here reduces the per-workgroup minima (one launch instead of two: the finishing kernel cost a
-    // launch and ~5 us in front of a host that waits for the decision)
-    __shared__ int last;
-    if (tid == 0) {
-        partial[blockIdx.x].min_ll = sh_ll[0]; partial[blockIdx.x].index = sh_ix[0];
-        __threadfence();                                             // the partial is visible before the ticket is drawn
-        last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    ll = INFINITY; ix = INT64_MAX;
-    for (int64_t i = tid; i < (int64_t)gridDim.x; i += kAssocBlock) {
-        const double pl = ((volatile AssocDecision *)partial)[i].min_ll;
-        const int64_t pi = ((volatile AssocDecision *)partial)[i].index;
-        if (assoc_better(pl, pi, ll, ix)) { ll = pl; ix = pi; }
-    }
-    sh_ll[tid] = ll; sh_ix[tid] = ix;
-    __syncthreads();
-    for (int s = kAssocBlock / 2; s > 0; s >>= 1) {
-        if (tid < s && assoc_better(sh_ll[tid + s], sh_ix[tid + s], sh_ll[tid], sh_ix[tid])) {
-            sh_ll[tid] = sh_ll[tid + s]; sh_ix[tid] = sh_ix[tid + s];
+        if (!last) return;
+        __threadfence();
+        if (tid < 64) {
+            ll = INFINITY; ix = INT64_MAX;
+            for (int64_t i = tid; i < (int64_t)gridDim.x; i += 64) {
+                const double pl = ((volatile AssocDecision *)partial)[i].min_ll;
+                const int64_t pi = ((volatile AssocDecision *)partial)[i].index;
+                if (assoc_better(pl, pi, ll, ix)) { ll = pl; ix = pi; }
+            }
+            wave_argmin(ll, ix);
         }
-        __syncthreads();
     }
+    // a map that fits one workgroup needs no partials, no ticket, no second reduction
     if (tid == 0) {
-        const bool found = sh_ix[0] != INT64_MAX;     // something passed the threshold (min_ll starts at Inf, :43)
+        const bool found = ix != INT64_MAX;           // something passed the threshold (min_ll starts at Inf, :43)
         AssocDecision d;
         d.is_new = found ? 0 : 1;
-        d.index = found ? sh_ix[0] : a.N;             // default index = numOfLandmarks + 1 (:40), 0-based here
-        d.min_ll = sh_ll[0];
+        d.index = found ? ix : a.N;                   // default index = numOfLandmarks + 1 (:40), 0-based here
+        d.min_ll = ll;
         d.seq = seq;
         *decision = d;
-        *ticket = 0;                                  // ready for the next launch (stream order)
-        if (cand) { cand[0] = sh_ll[0]; cand[1] = found ? (double)sh_ix[0] : -1.0; cand[2] = 0.0; cand[3] = 0.0; }
+        if (gridDim.x > 1) *ticket = 0;               // ready for the next launch (stream order)
+        if (cand) { cand[0] = ll; cand[1] = found ? (double)ix : -1.0; cand[2] = 0.0; cand[3] = 0.0; }
         if (host_decision) {
             // mapped host memory: payload first, then -- behind a system-scope fence -- the sequence number the host polls for
             volatile AssocDecision *hd = host_decision;
