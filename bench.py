@@ -357,6 +357,8 @@ def main():
                        "state_digest": [float(v) for v in head["digest"]]},
             "algorithmic_bytes_per_step": head["algorithmic_bytes_per_step"],
             "effective_GBps": head["effective_GBps"],
+            # SURVEY.md 8d's second unit: a SLAM iteration = 1 predict + m update-steps; here m = 1
+            "slam_iterations_per_s": head["value"], "update_steps_per_iteration": 1,
             "roofline": head["roofline"],
         }
         if dfr is not None:
