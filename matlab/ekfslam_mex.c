@@ -10,9 +10,9 @@
  * 0-based ones here.  Any non-zero status becomes mexErrMsgIdAndTxt('ekfslam:status', ...), so the .m classes
  * see MATLAB errors exactly where the reference's own code would raise them.
  *
- * Commands that take NO handle ('create', 'f') are dispatched before anything looks at prhs[1]; every other command
- * goes through handle_of(), which rejects an empty / non-uint64 / null handle with a MATLAB error instead of
- * dereferencing it.
+ * Commands that take NO single handle ('create', 'f', and 'exchange_local', whose second argument is a uint64 VECTOR of handles
+ * that it validates itself) are dispatched before anything looks at prhs[1] as a handle; every other command goes through
+ * handle_of(), which rejects an empty / non-uint64 / null handle with a MATLAB error instead of dereferencing it.
  */
 #include <stdint.h>
 #include <string.h>
@@ -45,7 +45,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("ekfslam:usage", "command string expected");
 
     /* ---- commands without a handle ---- */
-    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile [, batch]]) */
+    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile [, batch [, device, rank, world]]]) */
         ekf_config cfg;
         ekf_handle *h = NULL;
         need(nrhs, 3, cmd);
@@ -53,6 +53,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         cfg.capacity_landmarks = (int64_t)mxGetScalar(prhs[2]);
         if (nrhs > 3) cfg.tile = (int32_t)mxGetScalar(prhs[3]);
         if (nrhs > 4) cfg.batch = (int32_t)mxGetScalar(prhs[4]);      /* deferred downdate, same results */
+        if (nrhs > 5) {                                               /* one shard of a filter split over several GPUs */
+            need(nrhs, 8, cmd);
+            cfg.device = (int32_t)mxGetScalar(prhs[5]);
+            cfg.rank = (int32_t)mxGetScalar(prhs[6]);
+            cfg.world = (int32_t)mxGetScalar(prhs[7]);
+        }
         int32_t rc = ekf_create(&cfg, &h);
         if (rc != EKF_OK) {
             char msg[256];
@@ -76,6 +82,22 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         return;
     }
 
+    if (!strcmp(cmd, "exchange_local")) {         /* ekfslam_mex('exchange_local', handles): all shards of ONE filter, uint64 vector,
+                                                     each between the same *_begin and *_finish (include/ekfslam.h, transport (c)) */
+        ekf_handle *hs[64];
+        need(nrhs, 2, cmd);
+        if (!prhs[1] || mxGetClassID(prhs[1]) != mxUINT64_CLASS || !mxGetData(prhs[1]))
+            mexErrMsgIdAndTxt("ekfslam:handle", "exchange_local: a uint64 vector of handles expected");
+        const mwSize w = mxGetNumberOfElements(prhs[1]);
+        if (w < 1 || w > 64) mexErrMsgIdAndTxt("ekfslam:usage", "exchange_local: between 1 and 64 handles");
+        for (mwSize r = 0; r < w; ++r) {
+            hs[r] = (ekf_handle *)(uintptr_t)((const uint64_t *)mxGetData(prhs[1]))[r];
+            if (!hs[r]) mexErrMsgIdAndTxt("ekfslam:handle", "exchange_local: null handle in the vector");
+        }
+        check(hs[0], ekf_exchange_local(hs, (int32_t)w));
+        return;
+    }
+
     /* ---- everything below operates on a live handle ---- */
     ekf_handle *h = handle_of(nrhs, prhs);
     if (!strcmp(cmd, "destroy")) { ekf_destroy(h); mexUnlock(); return; }
@@ -95,6 +117,22 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
         if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)(idx + 1));
         return;
     }
+    /* sharded handles driven by one host thread: begin on every shard, 'exchange_local', finish on every shard */
+    if (!strcmp(cmd, "correct_begin")) { need(nrhs, 5, cmd); check(h, ekf_correct_begin(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetScalar(prhs[4]) - 1)); return; }
+    if (!strcmp(cmd, "correct_finish")) { check(h, ekf_correct_finish(h)); return; }
+    if (!strcmp(cmd, "associate_begin")) {        /* (h, z 1x3, R 2x2): candidates of this shard into its send area */
+        need(nrhs, 4, cmd);
+        check(h, ekf_associate_begin(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), 0));
+        return;
+    }
+    if (!strcmp(cmd, "associate_finish")) {       /* [newLL, index] = ...; index 1-based */
+        int32_t is_new; int64_t idx;
+        check(h, ekf_associate_finish(h, &is_new, &idx, NULL, NULL));
+        plhs[0] = mxCreateLogicalScalar(is_new != 0);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar((double)(idx + 1));
+        return;
+    }
+    if (!strcmp(cmd, "flush")) { check(h, ekf_flush(h)); return; }
     if (!strcmp(cmd, "measure")) {                /* (h, observed_LL m x 3, u, lm_index L x 1, lm_loc L x 2) */
         need(nrhs, 6, cmd);
         check(h, ekf_measure(h, mxGetPr(prhs[2]), (int64_t)mxGetM(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]),

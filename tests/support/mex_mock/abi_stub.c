@@ -7,7 +7,7 @@
 
 #include "ekfslam.h"
 
-struct ekf_handle { int64_t N, cap; int fail_next; char err[64]; };
+struct ekf_handle { int64_t N, cap; int fail_next; char err[64]; int rank, world; };
 
 #define LOG(...) do { printf("ABI " __VA_ARGS__); printf("\n"); } while (0)
 static int32_t st(ekf_handle *h) { if (h && h->fail_next) { h->fail_next = 0; snprintf(h->err, sizeof h->err, "injected failure"); return EKF_ERR_STATE; } return EKF_OK; }
@@ -23,6 +23,10 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     ekf_handle *h = calloc(1, sizeof *h);
     h->cap = cfg->capacity_landmarks; h->N = 0;
     *out = h;
+    h->rank = cfg->rank; h->world = cfg->world;
+    if (cfg->world > 1) LOG("ekf_create mode=%d cap=%lld tile=%d batch=%d device=%d rank=%d world=%d", cfg->mode,
+                            (long long)cfg->capacity_landmarks, cfg->tile, cfg->batch, cfg->device, cfg->rank, cfg->world);
+    else
     LOG("ekf_create mode=%d cap=%lld tile=%d batch=%d", cfg->mode, (long long)cfg->capacity_landmarks, cfg->tile, cfg->batch);
     if (cfg->capacity_landmarks == 666) { snprintf(h->err, sizeof h->err, "no device"); return EKF_ERR_NO_DEVICE; }
     return EKF_OK;
@@ -62,5 +66,19 @@ int32_t ekf_get_P_block(ekf_handle *h, int64_t r0, int64_t c0, int64_t nr, int64
     return st(h); }
 int32_t ekf_get_P_diag_blocks(ekf_handle *h, double *out) { LOG("ekf_get_P_diag_blocks"); for (int64_t i = 0; i < 4 * (h->N + 1); ++i) out[i] = 0.25 * i; return st(h); }
 int32_t ekf_get_Q(ekf_handle *h, double Q[9]) { LOG("ekf_get_Q"); for (int i = 0; i < 9; ++i) Q[i] = 10.0 + i; return st(h); }
+
+int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
+    LOG("ekf_correct_begin rank=%d z=%g,%g R=%g,%g,%g,%g idx0=%lld", h->rank, z[0], z[1], R[0], R[1], R[2], R[3], (long long)idx); return st(h); }
+int32_t ekf_correct_finish(ekf_handle *h) { LOG("ekf_correct_finish rank=%d", h->rank); return st(h); }
+int32_t ekf_associate_begin(ekf_handle *h, const double z[3], const double R[4], int32_t want_costs) {
+    LOG("ekf_associate_begin rank=%d z=%g,%g,%g R=%g,%g,%g,%g costs=%d", h->rank, z[0], z[1], z[2], R[0], R[1], R[2], R[3], want_costs); return st(h); }
+int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pc, double *sc) {
+    LOG("ekf_associate_finish rank=%d costs=%s", h->rank, (pc || sc) ? "yes" : "null"); *is_new = 0; *idx = 4; return st(h); }
+int32_t ekf_exchange_local(ekf_handle **hs, int32_t world) {
+    printf("ABI ekf_exchange_local world=%d ranks=", world);
+    for (int r = 0; r < world; ++r) printf("%s%d", r ? "," : "", hs[r]->rank);
+    printf("\n");
+    return st(hs[0]); }
+int32_t ekf_flush(ekf_handle *h) { LOG("ekf_flush"); return st(h); }
 
 void stub_fail_next(ekf_handle *h) { h->fail_next = 1; }

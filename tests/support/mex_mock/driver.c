@@ -82,6 +82,30 @@ int main(void) {
     call(1, 1, S("get_x"));
     call(0, 2, S("predict"), h);                                                      /* too few arguments */
     call(0, 2, S("no_such_command"), h);
+    /* one filter on two GPUs, one host thread (matlab/ShardedEKF.m): begin on every shard, exchange_local, finish on every shard */
+    call(1, 8, S("create"), D1(1), D1(32), D1(0), D1(1), D1(0), D1(0), D1(2));
+    mxArray *g0 = out[0];
+    call(1, 8, S("create"), D1(1), D1(32), D1(0), D1(1), D1(1), D1(1), D1(2));
+    mxArray *g1 = out[0];
+    const uint64_t hv[2] = { *(uint64_t *)mxGetData(g0), *(uint64_t *)mxGetData(g1) }, hbad[2] = { hv[0], 0 };
+    mxArray *gv = mock_uint64_vec(2, hv);
+    call(0, 5, S("correct_begin"), g0, mock_double(2, 1, z2), mock_double(2, 2, R), D1(3));
+    call(0, 5, S("correct_begin"), g1, mock_double(2, 1, z2), mock_double(2, 2, R), D1(3));
+    call(0, 2, S("exchange_local"), gv);
+    call(0, 2, S("correct_finish"), g0);
+    call(0, 2, S("correct_finish"), g1);
+    call(0, 4, S("associate_begin"), g0, mock_double(3, 1, z3), mock_double(2, 2, R));
+    call(0, 4, S("associate_begin"), g1, mock_double(3, 1, z3), mock_double(2, 2, R));
+    call(0, 2, S("exchange_local"), gv);
+    call(2, 2, S("associate_finish"), g0);
+    call(2, 2, S("associate_finish"), g1);
+    call(0, 2, S("flush"), g0);
+    call(0, 2, S("exchange_local"), mock_double(2, 1, u));                            /* not a handle vector */
+    call(0, 2, S("exchange_local"), mock_uint64_vec(2, hbad));                        /* a null handle inside */
+    call(0, 2, S("exchange_local"), empty);
+    call(1, 6, S("create"), D1(1), D1(32), D1(0), D1(1), D1(0));                      /* device without rank / world */
+    call(0, 2, S("destroy"), g1);
+    call(0, 2, S("destroy"), g0);
     call(0, 2, S("destroy"), h2);
     call(0, 2, S("destroy"), h);
     printf("LOCKS %d\nMISUSE %d\n", mock_lock_count, mock_misuse);

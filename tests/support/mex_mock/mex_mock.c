@@ -27,6 +27,11 @@ mxArray *mock_double(size_t m, size_t n, const double *v) {
 }
 mxArray *mock_string(const char *s) { mxArray *a = calloc(1, sizeof *a); a->cls = mxUNKNOWN_CLASS; a->str = malloc(strlen(s) + 1); strcpy(a->str, s); a->m = 1; a->n = strlen(s); return a; }
 mxArray *mock_uint64(uint64_t v) { mxArray *a = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL); *(uint64_t *)a->data = v; return a; }
+mxArray *mock_uint64_vec(size_t n, const uint64_t *v) {
+    mxArray *a = mxCreateNumericMatrix(n, 1, mxUINT64_CLASS, mxREAL);
+    for (size_t i = 0; i < n; ++i) ((uint64_t *)a->data)[i] = v[i];
+    return a;
+}
 int mock_is_logical(const mxArray *a) { return a->logical; }
 
 mxClassID mxGetClassID(const mxArray *pa) { return pa->cls; }

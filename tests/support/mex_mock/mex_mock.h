@@ -10,5 +10,6 @@ extern int mock_lock_count, mock_misuse;
 mxArray *mock_double(size_t m, size_t n, const double *v);
 mxArray *mock_string(const char *s);
 mxArray *mock_uint64(uint64_t v);
+mxArray *mock_uint64_vec(size_t n, const uint64_t *v);
 int mock_is_logical(const mxArray *a);
 #endif

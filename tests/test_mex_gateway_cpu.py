@@ -105,7 +105,17 @@ def test_gateway_marshalling_under_the_mock(transcript):
     # errors: a failing status carries ekf_last_error; handles are validated, never dereferenced blindly
     assert "MEX predict nrhs=3 -> ERROR ekfslam:status | call not valid in the current state: injected failure" in t
     bad = [ln for ln in t if "ERROR ekfslam:handle" in ln]
-    assert len(bad) == 4                                  # [] handle, double handle, null uint64, missing handle
+    assert len(bad) == 7                                  # [] handle, double handle, null uint64, missing handle; exchange_local: doubles, a null inside, []
+    # several GPUs from one host thread (matlab/ShardedEKF.m): device / rank / world reach the config; begin on every shard,
+    # ONE exchange over the handle vector in shard order, finish on every shard; 1-based index converted once
+    assert "ABI ekf_create mode=1 cap=32 tile=0 batch=1 device=1 rank=1 world=2" in t
+    i = t.index("ABI ekf_exchange_local world=2 ranks=0,1")
+    assert [ln.split()[1] for ln in t[i - 4:i + 5] if ln.startswith("ABI ")] == \
+        ["ekf_correct_begin", "ekf_correct_begin", "ekf_exchange_local", "ekf_correct_finish", "ekf_correct_finish"]
+    assert "ABI ekf_correct_begin rank=1 z=5,50 R=0.05,0,0,250 idx0=2" in t
+    assert "ABI ekf_associate_begin rank=0 z=5,50,7 R=0.05,0,0,250 costs=0" in t
+    assert any(ln.startswith("MEX associate_finish") and "out0=1x1L[0] out1=1x1[5]" in ln for ln in t)
+    assert any(ln.startswith("MEX create nrhs=6 -> ERROR ekfslam:usage") for ln in t)
     assert any("ERROR ekfslam:usage | 'predict' needs 3 arguments" in ln for ln in t)
     assert any("unknown command 'no_such_command'" in ln for ln in t)
     assert t[-2:] == ["LOCKS 0", "MISUSE 0"]              # create/destroy balance mexLock; no mxGetScalar on an empty array
@@ -122,12 +132,18 @@ def test_no_command_reads_the_handle_before_it_is_known_to_be_one():
     body = src[src.index("void mexFunction("):]
     at = body.index("handle_of(nrhs, prhs)")
     before = body[:at]
-    # the only commands dispatched before the handle is validated are the two that take none, and each of them returns
-    assert re.findall(r'strcmp\(cmd, "([A-Za-z_]+)"\)', before) == ["create", "f"]
-    assert before.count("return;") >= 2
-    # and nothing there turns prhs[1] into a pointer (create reads it as the numeric mode argument: mxGetScalar only)
-    assert not re.search(r"mxGet(Data|Pr)\(prhs\[1\]\)", before)
-    assert "mxGetData(prhs[1])" not in body[at:].replace("handle_of(nrhs, prhs)", "")    # only handle_of() touches it
+    # the only commands dispatched before the handle is validated are the two that take none and the one that takes a VECTOR
+    # of handles, and each of them returns
+    assert re.findall(r'strcmp\(cmd, "([A-Za-z_]+)"\)', before) == ["create", "f", "exchange_local"]
+    assert before.count("return;") >= 3
+    # create / f never turn prhs[1] into a pointer (create reads it as the numeric mode argument: mxGetScalar only) ...
+    xl = before.index('strcmp(cmd, "exchange_local")')
+    assert not re.search(r"mxGet(Data|Pr)\(prhs\[1\]\)", before[:xl])
+    # ... and exchange_local checks class and data pointer before it reads the vector, and every element before it is used
+    blk = before[xl:]
+    assert blk.index("mxGetClassID(prhs[1]) != mxUINT64_CLASS") < blk.index("(const uint64_t *)mxGetData(prhs[1])")
+    assert blk.index("if (!hs[r])") < blk.index("ekf_exchange_local(hs")
+    assert "mxGetData(prhs[1])" not in body[at:].replace("handle_of(nrhs, prhs)", "")    # after that only handle_of() touches it
 
 
 def _m_class(name):
