@@ -801,7 +801,11 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     };
     const double2 up0 = load_up(tid), up1 = load_up(tid + kGatherCols);
     __builtin_amdgcn_sched_barrier(0);      // keep these loads AHEAD of the per-column ones below (in-order return)
-    EKF_STAMP();                                                  // a: uniform operands requested
+    // barrier 0 (see the helper path): flags reset.  HERE, before the per-column loads: their address arithmetic takes ~1 200
+    // clocks, and the CHAIN wavefront -- the critical path of the launch -- would stand at this barrier for all of them (it did:
+    // the column lanes then waited ~2 000 clocks for the solve at barrier B).  No waitcnt: the loads stay in flight across it.
+    asm volatile("s_barrier" ::: "memory");
+    EKF_STAMP();                                                  // a: uniform operands requested, barrier 0 passed
     //     Then what this column needs: the two landmark rows at column c (canonical lower-triangle entries: row part left of
     //     j, column part right of j+1 -- one 16-byte load there, j is even; from the tiles or from the exchanged row-panel),
     //     the strip column, x(c) ...
@@ -820,7 +824,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         xc = x[3 + c];
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");                       // barrier 0 (see the helper path): flags reset, loads still in flight
     EKF_STAMP();                                                  // b: all loads requested
     // (2) stage the uniform operands (waits for the FIRST group of loads only); the four column wavefronts and DIAG meet on a
     //     counter in LDS -- the CHAIN and BEARING wavefronts do not take part

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B the gather kernel's rocprofv3 average duration on ONE box: scripts/ab_gather.sh <outdir> "label|lib-or--" ...
+# A/B the gather kernel's rocprofv3 average duration on ONE box: [BATCH=32 BATCHES=12] scripts/ab_gather.sh <outdir> "label|lib-or--" ...
 OUT=$1; shift
 mkdir -p $OUT
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -8,7 +8,7 @@ for r in 1 2; do
   for v in "$@"; do
     IFS='|' read -r label lib <<< "$v"
     if [ "$lib" != "-" ]; then export EKF_LIB_PATH=$REPO/$lib; else unset EKF_LIB_PATH; fi
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$label.$r -- python3 $REPO/scripts/time_flush.py --batch 32 --batches 12 --label $label > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$label.$r -- python3 $REPO/scripts/time_flush.py --batch ${BATCH:-32} --batches ${BATCHES:-12} --label $label > /dev/null 2>&1
     f=$(find $OUT/$label.$r -name "*kernel_stats.csv" | head -1)
     python3 - "$f" "$label" <<'PY'
 import csv, sys

@@ -10,7 +10,7 @@ from ekf_slam_amd import Engine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 view = sys.argv[3] if len(sys.argv) > 3 else "columns"
-names = {"columns": ["uniform loads issued", "column loads issued + barrier 0", "upatch staged by all", "pair operands + patches", "wait for the solve (barrier B)", "outputs"],
+names = {"columns": ["uniform loads issued + barrier 0", "column loads issued", "upatch staged by all", "pair operands + patches", "wait for the solve (barrier B)", "outputs"],
          "diag": ["loads issued + barrier 0", "own block arrived", "operands staged", "patch chain + flag", "small outputs + barrier B"],
          "chain": ["loads issued + barrier 0", "own operands arrived", "sincos", "predict entries", "H_s", "diag wait+GS+phi+inv", "publish + barrier B"]}[view]
 NST = len(names) + 1
