@@ -102,14 +102,18 @@ struct ekf_handle {
     int2 *d_work_xcd = nullptr;
     int64_t xcd_len = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
-    AssocDecision *h_decision_dev = nullptr;   // device-side address of the mapped h_decision (the association kernel writes it)
-    int *d_ticket = nullptr;                   // k_associate's last-workgroup ticket
+    AssocDecision *h_decision_dev = nullptr;   // device-side address of the mapped h_decision (k_assoc_merge, the sharded path, writes it)
+    int *d_ticket = nullptr;                   // k_associate's last-workgroup ticket (device-side consumers only)
     int32_t assoc_seq = 0;
-    // cfg.device_assoc == 2: measure() dispatches on the host mirror's decision while k_associate runs for every observation in
-    // the stream; its decisions land in this mapped ring and are VERIFIED against the host's before measure() returns
+    // k_associate's workgroups store their winners into MAPPED host memory and the host takes the arg-min: kSpecRing + 1 sets of
+    // parts_stride entries (one per workgroup at capacity).  Sets 0..kSpecRing-1 form the ring of cfg.device_assoc == 2 (measure()
+    // dispatches on the host mirror's decision while k_associate runs for every observation in the stream; the device's decisions
+    // are VERIFIED against the host's before measure() returns); set kSpecRing serves the calls that wait for their decision.
     static constexpr int kSpecRing = 64;
-    AssocDecision *h_spec = nullptr, *h_spec_dev = nullptr;
-    struct Spec { int32_t seq, is_new; int64_t idx; };
+    AssocHostPartial *h_parts = nullptr, *h_parts_dev = nullptr;
+    int64_t parts_stride = 0;
+    bool assoc_poll = true;                    // EKF_ASSOC_POLL=0: wait by stream synchronisation instead of polling the mapped entries
+    struct Spec { int32_t seq, is_new, nblk; int64_t idx, idx_N; };   // idx_N: landmarks at launch (the default index of a new one)
     std::vector<Spec> spec;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
@@ -571,10 +575,49 @@ bool wait_mapped_seq(volatile AssocDecision *slot, int32_t seq) {
     return false;
 }
 
+inline int32_t assoc_blocks(int64_t N) { return (int32_t)((N + kAssocBlock - 1) / kAssocBlock); }
+
+// all nblk workgroups of launch `seq` have stored their winner (each entry is ONE 16-byte store: seq and payload arrive together)
+bool wait_parts(volatile AssocHostPartial *set, int32_t nblk, int32_t seq) {
+    int32_t b = 0;
+    for (int spin = 0; spin < 2000000; ++spin) {
+        while (b < nblk && set[b].seq == seq) ++b;
+        if (b == nblk) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
+        __builtin_ia32_pause();
+    }
+    return false;
+}
+
+// Correspondence.m:78-85 over the workgroups' winners: lowest likelihood, lowest index on ties (the order of the kernel's own
+// reductions); nothing below the threshold anywhere -> new landmark, index N (0-based)
+int32_t reduce_parts(ekf_handle *h, volatile AssocHostPartial *set, int32_t nblk, int32_t seq, int64_t N, int32_t *is_new, int64_t *idx) {
+    double best = INFINITY;
+    int64_t at = -1;
+    for (int32_t b = 0; b < nblk; ++b) {
+        REQUIRE(h, set[b].seq == seq, EKF_ERR_STATE, "associate: a workgroup's result is missing from the mapped buffer");
+        const double ll = set[b].min_ll;
+        const int64_t ix = set[b].index;
+        if (ix >= 0 && (at < 0 || ll < best || (ll == best && ix < at))) { best = ll; at = ix; }
+    }
+    *is_new = at < 0 ? 1 : 0;
+    *idx = at < 0 ? N : at;
+    return EKF_OK;
+}
+
+// the decision of launch `seq` (nblk workgroups, entries in `set`): poll, or synchronise the stream, then reduce
+int32_t collect_decision(ekf_handle *h, AssocHostPartial *set, int32_t nblk, int32_t seq, int64_t N, bool may_poll, int32_t *is_new,
+                         int64_t *idx) {
+    if (!(may_poll && h->assoc_poll && wait_parts(set, nblk, seq))) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));            // the kernel has retired: its stores to mapped memory are complete
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    return reduce_parts(h, set, nblk, seq, N, is_new, idx);
+}
+
 // exchange == false: the decision of this launch is final (unsharded, or sharded with the signature-only likelihood, which every
 // shard evaluates identically from replicated data); exchange == true (sharded): this shard nominates among the landmarks whose
 // diagonal block it holds and leaves its candidate -- and, want_costs, their position costs -- in the send area
-int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocDecision *host_slot_dev, int32_t seq,
+int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocHostPartial *host_set_dev, int32_t seq,
                      bool exchange = false, bool want_costs = false) {
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
     REQUIRE(h, exchange || h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
@@ -592,7 +635,7 @@ int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocD
     a.own_only = exchange ? 1 : 0;
     TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
     HIPCHK(h, launch_associate(h->st, a, exchange ? (want_costs ? h->send + 4 : nullptr) : h->d_pos_cost, h->d_sig_cost,
-                               h->d_partial, h->d_ticket, h->d_decision, exchange ? nullptr : host_slot_dev, seq,
+                               h->d_partial, h->d_ticket, h->d_decision, exchange ? nullptr : host_set_dev, seq,
                                exchange ? h->send : nullptr, h->storage, h->stream));
     return EKF_OK;
 }
@@ -631,15 +674,22 @@ int32_t assoc_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pos_c
 int32_t verify_speculated(ekf_handle *h) {
     if (h->spec.empty()) return EKF_OK;
     const size_t n = h->spec.size();
-    volatile AssocDecision *last = h->h_spec + ((n - 1) % ekf_handle::kSpecRing);
-    if (!wait_mapped_seq(last, h->spec[n - 1].seq)) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));            // the kernels have retired: the mapped writes are complete
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    // wait for the NEWEST launch only: once its workgroups have reported, the launches queued before it on the same stream have
+    // retired and their stores (posted in order) have landed
+    {
+        const ekf_handle::Spec &sp = h->spec[n - 1];
+        AssocHostPartial *set = h->h_parts + (int64_t)((n - 1) % ekf_handle::kSpecRing) * h->parts_stride;
+        if (!(h->assoc_poll && wait_parts(set, sp.nblk, sp.seq))) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
     }
     int32_t rc = EKF_OK;
     for (size_t q = 0; q < n && !rc; ++q) {
-        const volatile AssocDecision *d = h->h_spec + (q % ekf_handle::kSpecRing);
-        if (d->seq != h->spec[q].seq || d->is_new != h->spec[q].is_new || d->index != h->spec[q].idx)
+        const ekf_handle::Spec &sp = h->spec[q];
+        int32_t is_new = 0; int64_t idx = 0;
+        rc = reduce_parts(h, h->h_parts + (int64_t)(q % ekf_handle::kSpecRing) * h->parts_stride, sp.nblk, sp.seq, sp.idx_N, &is_new, &idx);
+        if (!rc && (is_new != sp.is_new || idx != sp.idx))
             rc = fail(h, EKF_ERR_STATE, "measure: the device association disagrees with the host mirror of the signatures");
     }
     h->spec.clear();
@@ -661,21 +711,17 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
         return assoc_finish(h, is_new, idx, pos_cost, sig_cost);
     }
     const int32_t seq = next_assoc_seq(h);
-    int32_t rc = launch_assoc(h, z, R, h->h_decision_dev, seq);
+    const int64_t N = h->N;
+    AssocHostPartial *set = h->h_parts + (int64_t)ekf_handle::kSpecRing * h->parts_stride;
+    int32_t rc = launch_assoc(h, z, R, h->h_parts_dev + (int64_t)ekf_handle::kSpecRing * h->parts_stride, seq);
     if (rc) return rc;
-    if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    // measure()'s path: the kernel writes the decision into mapped host memory (sequence number last, behind a system-scope
-    // fence); polling for it costs ~2 us after the kernel retires, a device->host copy + stream synchronisation ~15 us.
-    // Bounded: after ~2 ms the ordinary path below takes over.
-    const bool have = h->h_decision_dev && !pos_cost && !sig_cost && wait_mapped_seq(h->h_decision, seq);
-    if (!have) {
-        HIPCHK(h, hipMemcpyAsync(h->h_decision, h->d_decision, sizeof(AssocDecision), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    *is_new = h->h_decision->is_new;
-    *idx = h->h_decision->index;
-    return EKF_OK;
+    if (pos_cost) HIPCHK(h, hipMemcpyAsync(pos_cost, h->d_pos_cost, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    if (sig_cost) HIPCHK(h, hipMemcpyAsync(sig_cost, h->d_sig_cost, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    // measure()'s path: every workgroup stores its winner into mapped host memory (one 16-byte store: payload + sequence number)
+    // and the host takes the arg-min as soon as all of them carry this launch's number -- ~2 us after the kernel's last store,
+    // against ~15 us for a device->host copy + stream synchronisation.  Bounded: after ~2 ms the stream is synchronised instead.
+    // With cost vectors asked for the copies above need the synchronisation anyway.
+    return collect_decision(h, set, assoc_blocks(N), seq, N, !pos_cost && !sig_cost, is_new, idx);
 }
 
 // Correspondence.m:40-43,71,75,78-85 with the live likelihood (signature cost only)
@@ -880,12 +926,18 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         void *dp = nullptr;
         if (poll && hipHostGetDevicePointer(&dp, h->h_decision, 0) == hipSuccess) h->h_decision_dev = (AssocDecision *)dp;
     }
-    if (cfg->device_assoc == 2) {
-        HIPCHK(h, hipHostMalloc((void **)&h->h_spec, sizeof(AssocDecision) * ekf_handle::kSpecRing, hipHostMallocMapped));
-        memset(h->h_spec, 0, sizeof(AssocDecision) * ekf_handle::kSpecRing);
+    {
+        // k_associate's per-workgroup winners (see ekf_handle::h_parts): kSpecRing sets for cfg.device_assoc == 2, one more for
+        // the calls that wait; 16 bytes per workgroup at capacity
+        static const bool poll = [] { const char *v = getenv("EKF_ASSOC_POLL"); return !v || atoi(v) != 0; }();
+        h->assoc_poll = poll;
+        h->parts_stride = assoc_blocks(h->cap > 0 ? h->cap : 1);
+        const size_t bytes = sizeof(AssocHostPartial) * (size_t)h->parts_stride * (ekf_handle::kSpecRing + 1);
+        HIPCHK(h, hipHostMalloc((void **)&h->h_parts, bytes, hipHostMallocMapped));
+        memset(h->h_parts, 0, bytes);                                   // sequence numbers start at 1: 0 marks "never written"
         void *dp = nullptr;
-        HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_spec, 0));
-        h->h_spec_dev = (AssocDecision *)dp;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_parts, 0));
+        h->h_parts_dev = (AssocHostPartial *)dp;
     }
     HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
 
@@ -913,7 +965,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);
-    if (h->h_spec) hipHostFree(h->h_spec);
+    if (h->h_parts) hipHostFree(h->h_parts);
     if (h->h_small) hipHostFree(h->h_small);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -1059,15 +1111,15 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
                 // the host mirror of s -- same arithmetic as k_associate, no launch, no device->host sync.
                 // ekf_associate() always runs the full device computation.
                 associate_signature_only(h, z[2], &is_new, &idx);
-                if (h->cfg.device_assoc == 2 && h->h_spec_dev) {
+                if (h->cfg.device_assoc == 2) {
                     // ... and with device_assoc == 2 the device evaluates the association all the same (per-landmark phi_k,
                     // Mahalanobis and signature cost, arg-min), queued behind the previous row's kernels; the host does not wait
                     // for it but checks every decision against its own before measure() returns
                     if ((int)h->spec.size() == ekf_handle::kSpecRing) { rc = verify_speculated(h); if (rc) return rc; }
                     const int32_t seq = next_assoc_seq(h);
-                    rc = launch_assoc(h, z, R, h->h_spec_dev + (h->spec.size() % ekf_handle::kSpecRing), seq);
+                    rc = launch_assoc(h, z, R, h->h_parts_dev + (int64_t)(h->spec.size() % ekf_handle::kSpecRing) * h->parts_stride, seq);
                     if (rc) { verify_speculated(h); return rc; }
-                    h->spec.push_back({ seq, is_new, idx });
+                    h->spec.push_back({ seq, is_new, assoc_blocks(h->N), idx, h->N });
                 }
             } else {
                 rc = do_associate(h, z, R, &is_new, &idx, nullptr, nullptr);   // EKF_SLAM_UC.m:119

@@ -70,6 +70,14 @@ struct AssocDecision {        // written by the device, read back by the host
     double  min_ll;
 };
 
+// One workgroup's winner, as it lands in MAPPED HOST memory: 16 bytes written by ONE store instruction of one lane (payload and
+// sequence number arrive together; the host reads `seq` first, then the payload).  index: 0-based, -1 = nothing passed the threshold.
+struct alignas(16) AssocHostPartial {
+    double  min_ll;
+    int32_t index;
+    int32_t seq;
+};
+
 constexpr int kAssocBlock = 256;       // 4 wavefronts = one per SIMD: the per-landmark solve is a dependent f64 chain (1024 measured slower: 16 wavefronts share one CU's f64 issue)
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
@@ -106,10 +114,11 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries; ticket: a
 // device int, zero between launches (the last workgroup to finish reduces the partials and resets it: one launch, no
-// finishing kernel); decision: device copy; host_decision: nullptr or a host-MAPPED copy the kernel writes as well, its `seq`
-// field last, behind a system-scope fence (the host polls for seq == `seq`)
+// finishing kernel); decision: device copy.  host_partials != nullptr (mapped host memory, one entry per workgroup): NO cross-workgroup
+// step on the device at all -- every workgroup stores its winner there and the HOST takes the arg-min over the ceil(N / kAssocBlock)
+// entries once each carries `seq` (the ticket + release / acquire hand-over it replaces was ~4 of the kernel's 9 us)
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
-                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
+                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocHostPartial *host_partials, int seq,
                             double *cand, int storage, hipStream_t s);
 // cand (nullptr or 4 device doubles): this shard's candidate {likelihood, index or -1, 0, 0} for the all-gather of a sharded
 // association; launch_assoc_merge takes the arg-min over the `world` gathered contributions of `count` doubles each (candidate,

@@ -1201,7 +1201,7 @@ template <typename TS>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
                                                            AssocDecision *partial, int *ticket, AssocDecision *__restrict__ decision,
-                                                           AssocDecision *host_decision, int seq, double *__restrict__ cand) {
+                                                           AssocHostPartial *host_partials, int seq, double *__restrict__ cand) {
     __shared__ double sh_ll[kAssocBlock / 64];
     __shared__ int64_t sh_ix[kAssocBlock / 64];
     const int tid = threadIdx.x;
@@ -1272,19 +1272,36 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         ix = tid < kAssocBlock / 64 ? sh_ix[tid] : INT64_MAX;
         wave_argmin(ll, ix);
     }
+    if (host_partials) {
+        // The HOST takes the arg-min over the workgroups' winners: ONE 16-byte store per workgroup into mapped host memory, payload
+        // and sequence number together -- no ticket, no fence, no second reduction on the device.
+        if (tid == 0) {
+            typedef int part_v4 __attribute__((ext_vector_type(4)));
+            part_v4 v;
+            const long long lb = __double_as_longlong(ll);
+            v.x = (int)(lb & 0xffffffffll); v.y = (int)(lb >> 32);
+            v.z = ix == INT64_MAX ? -1 : (int)ix; v.w = seq;
+            *reinterpret_cast<part_v4 *>(host_partials + blockIdx.x) = v;
+        }
+        return;
+    }
     if (gridDim.x > 1) {
-        // several workgroups: the LAST one to get here reduces the per-workgroup minima (one launch instead of two: a finishing
-        // kernel cost a launch and ~5 us in front of a host that waits for the decision)
+        // several workgroups and a consumer on the DEVICE (the sharded exchange's candidate): the LAST workgroup to get here
+        // reduces the per-workgroup minima.
+        // Hand-over of the partials, release / acquire at agent scope around the ticket: ONE lane releases (write-back of this
+        // XCD's L2, ~1.7 us) and, in the last workgroup, ONE wavefront acquires (L1 invalidate) before it reads them.  The full
+        // __threadfence() on both sides that stood here first -- write-back AND invalidate, the second one by all 256 threads --
+        // was most of this kernel's 9 us (MI355X_MICROARCH.md: ~3.5 us per fence, 2-3.8x that with a whole workgroup fencing).
         __shared__ int last;
         if (tid == 0) {
             partial[blockIdx.x].min_ll = ll; partial[blockIdx.x].index = ix;
-            __threadfence();                                         // the partial is visible before the ticket is drawn
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the partial is visible before the ticket is drawn
             last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
         }
         __syncthreads();
         if (!last) return;
-        __threadfence();
         if (tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // this wavefront's loads below see every workgroup's partial
             ll = INFINITY; ix = INT64_MAX;
             for (int64_t i = tid; i < (int64_t)gridDim.x; i += 64) {
                 const double pl = ((volatile AssocDecision *)partial)[i].min_ll;
@@ -1305,13 +1322,6 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         *decision = d;
         if (gridDim.x > 1) *ticket = 0;               // ready for the next launch (stream order)
         if (cand) { cand[0] = ll; cand[1] = found ? (double)ix : -1.0; cand[2] = 0.0; cand[3] = 0.0; }
-        if (host_decision) {
-            // mapped host memory: payload first, then -- behind a system-scope fence -- the sequence number the host polls for
-            volatile AssocDecision *hd = host_decision;
-            hd->index = d.index; hd->is_new = d.is_new; hd->min_ll = d.min_ll;
-            __threadfence_system();
-            hd->seq = seq;
-        }
     }
 }
 
@@ -1935,14 +1945,14 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
-                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocDecision *host_decision, int seq,
+                            AssocDecision *partial, int *ticket, AssocDecision *decision, AssocHostPartial *host_partials, int seq,
                             double *cand, int storage, hipStream_t s) {
     const int64_t grid = cdiv(a.N > 0 ? a.N : 1, kAssocBlock);
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_decision, seq, cand),
+                           decision, host_partials, seq, cand),
         hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_decision, seq, cand));
+                           decision, host_partials, seq, cand));
     return hipGetLastError();
 }
 
