@@ -577,11 +577,23 @@ bool wait_mapped_seq(volatile AssocDecision *slot, int32_t seq) {
 
 inline int32_t assoc_blocks(int64_t N) { return (int32_t)((N + kAssocBlock - 1) / kAssocBlock); }
 
-// all nblk workgroups of launch `seq` have stored their winner (each entry is ONE 16-byte store: seq and payload arrive together)
+// one snapshot of a mapped entry: payload, and the launch sequence number its tag stands for GIVEN that payload
+struct PartView { double ll; int32_t index; int32_t seq; };
+inline PartView read_part(const volatile AssocHostPartial *e) {
+    const volatile uint64_t *w = reinterpret_cast<const volatile uint64_t *>(e);
+    const uint64_t lo = w[0], hi = w[1];
+    PartView v;
+    memcpy(&v.ll, &lo, 8);
+    v.index = (int32_t)(uint32_t)(hi & 0xffffffffu);
+    v.seq = (int32_t)((uint32_t)(hi >> 32) - assoc_part_mix((uint32_t)(lo & 0xffffffffu), (uint32_t)(lo >> 32), (uint32_t)v.index));
+    return v;
+}
+
+// all nblk workgroups of launch `seq` have stored their winner (self-validating entries: kernels.h)
 bool wait_parts(volatile AssocHostPartial *set, int32_t nblk, int32_t seq) {
     int32_t b = 0;
     for (int spin = 0; spin < 2000000; ++spin) {
-        while (b < nblk && set[b].seq == seq) ++b;
+        while (b < nblk && read_part(set + b).seq == seq) ++b;
         if (b == nblk) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
         __builtin_ia32_pause();
     }
@@ -594,9 +606,10 @@ int32_t reduce_parts(ekf_handle *h, volatile AssocHostPartial *set, int32_t nblk
     double best = INFINITY;
     int64_t at = -1;
     for (int32_t b = 0; b < nblk; ++b) {
-        REQUIRE(h, set[b].seq == seq, EKF_ERR_STATE, "associate: a workgroup's result is missing from the mapped buffer");
-        const double ll = set[b].min_ll;
-        const int64_t ix = set[b].index;
+        const PartView v = read_part(set + b);
+        REQUIRE(h, v.seq == seq, EKF_ERR_STATE, "associate: a workgroup's result is missing from the mapped buffer");
+        const double ll = v.ll;
+        const int64_t ix = v.index;
         if (ix >= 0 && (at < 0 || ll < best || (ll == best && ix < at))) { best = ll; at = ix; }
     }
     *is_new = at < 0 ? 1 : 0;
@@ -934,7 +947,9 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         h->parts_stride = assoc_blocks(h->cap > 0 ? h->cap : 1);
         const size_t bytes = sizeof(AssocHostPartial) * (size_t)h->parts_stride * (ekf_handle::kSpecRing + 1);
         HIPCHK(h, hipHostMalloc((void **)&h->h_parts, bytes, hipHostMallocMapped));
-        memset(h->h_parts, 0, bytes);                                   // sequence numbers start at 1: 0 marks "never written"
+        memset(h->h_parts, 0, bytes);
+        // sequence numbers start at 1: an entry that was never written must read as launch 0
+        for (size_t e = 0; e < (size_t)h->parts_stride * (ekf_handle::kSpecRing + 1); ++e) h->h_parts[e].tag = (int32_t)assoc_part_mix(0, 0, 0);
         void *dp = nullptr;
         HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_parts, 0));
         h->h_parts_dev = (AssocHostPartial *)dp;

@@ -75,8 +75,19 @@ struct AssocDecision {        // written by the device, read back by the host
 struct alignas(16) AssocHostPartial {
     double  min_ll;
     int32_t index;
-    int32_t seq;
+    int32_t tag;       // launch sequence number + assoc_part_mix(payload): see below
 };
+// The 16 bytes leave the GPU in one store instruction and have been observed to land whole, but that is not an architectural
+// promise -- so the entry validates itself: tag = seq + mix(payload).  A reader that sees a torn entry (new tag, old payload or
+// the reverse) computes a sequence number that is not the one it waits for (up to a 2^-32 coincidence) and simply polls again.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t assoc_part_mix(uint32_t ll_lo, uint32_t ll_hi, uint32_t index) {
+    uint32_t m = ll_lo * 0x9E3779B1u ^ (ll_hi + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (index + 0x165667B1u) * 0xC2B2AE35u;
+    m ^= m >> 15; m *= 0x2C1B3C6Du; m ^= m >> 13;
+    return m;
+}
 
 constexpr int kAssocBlock = 256;       // 4 wavefronts = one per SIMD: the per-landmark solve is a dependent f64 chain (1024 measured slower: 16 wavefronts share one CU's f64 issue)
 

@@ -1280,7 +1280,8 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
             part_v4 v;
             const long long lb = __double_as_longlong(ll);
             v.x = (int)(lb & 0xffffffffll); v.y = (int)(lb >> 32);
-            v.z = ix == INT64_MAX ? -1 : (int)ix; v.w = seq;
+            v.z = ix == INT64_MAX ? -1 : (int)ix;
+            v.w = (int)((uint32_t)seq + assoc_part_mix((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z));
             *reinterpret_cast<part_v4 *>(host_partials + blockIdx.x) = v;
         }
         return;
