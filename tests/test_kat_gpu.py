@@ -1,6 +1,7 @@
-"""GPU twins of the hand-derived known-answer tests KAT-5..7 (derivations: tests/kat_cases.py; CPU side:
-tests/test_oracle_kat.py): the HIP path, through the C ABI, against values worked out on paper from EKF_SLAM.m:67-98,
-:124-145 and Correspondence.m:49-87 -- the one pin that does not pass through the builder's own restatements."""
+"""GPU twins of the hand-derived known-answer tests KAT-5..12 (derivations: tests/kat_cases.py; CPU side:
+tests/test_oracle_kat.py): the HIP path, through the C ABI, against values worked out on paper from EKF_SLAM.m:40-65,
+:67-98, :124-145, EKF_SLAM_UC.m:102-152 and Correspondence.m:49-87 -- the one pin that does not pass through the builder's
+own restatements.  KAT-8..12 sit at headings 90 / 180 / 270."""
 import numpy as np
 import pytest
 
@@ -70,3 +71,107 @@ def test_kat7_correspondence_class_forwards_cost_and_threshold():
         == (True, 3)                                   # signature cost (6-5)^2/1 = 1 > 0.5 for both -> new landmark N+1
     with pytest.warns(UserWarning):
         assert Correspondence(1.0, 1e9, 'other').method == 'ML'
+
+
+# ---- KAT-8..12: non-zero headings, two corrections in a row, the UC new-landmark dispatch ----
+_SHAPES = [(16, 1), (128, 1), (16, 4), (0, 8)]          # (tile, batch): small and production tiles, immediate and deferred
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+@pytest.mark.parametrize("lazy", [False, True])
+def test_kat8_predict_at_heading_90_on_the_gpu(tile, batch, lazy):
+    """lazy: the predict stays recorded and is folded into the next correction's gather kernel (checked through KAT-9's
+    arithmetic being untouched: x and P are read right after, which launches the standalone predict) -- both forms."""
+    from ekf_slam_amd import Engine
+    e = Engine(capacity=4, tile=tile, batch=batch)
+    e.set_state(K.K8_X, K.K8_P, [1.0])
+    e.predict(K.K8_U)
+    if not lazy:
+        np.testing.assert_array_equal(e.get_x(), K.K8_X_OUT)
+        np.testing.assert_allclose(e.get_P(), K.K8_P_OUT, rtol=0, atol=3e-13)
+        np.testing.assert_allclose(e.get_Q3(), K.K8_Q_OUT, rtol=0, atol=3e-13)
+    else:
+        # fold the predict into a correction's gather, then undo nothing: compare with predict-then-correct of the dense oracle's
+        # arithmetic by running the same correction on an engine loaded with the hand-derived post-predict state
+        z, R = [2.0, 10.0], np.diag([.02, 50.0])
+        e.correct(z, R, 0)
+        ref = Engine(capacity=4, tile=tile, batch=batch)
+        ref.set_state(K.K8_X_OUT, K.K8_P_OUT, [1.0])
+        ref.correct(z, R, 0)
+        np.testing.assert_allclose(e.get_x(), ref.get_x(), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(e.get_P(), ref.get_P(), rtol=0, atol=1e-12)
+        ref.close()
+    e.close()
+
+
+def test_kat8_public_f_on_the_host_function():
+    from ekf_slam_amd.slam import EKF_SLAM
+    h = EKF_SLAM(capacity=4)
+    x_new, F = h.f(K.K8_X, K.K8_U)                     # EKF_SLAM.m:56-65: F(1,3) = -2 sind(90), F(2,3) = 2 cosd(90)
+    np.testing.assert_array_equal(x_new, [-1, 2, 180, 3, 4])
+    Fw = np.eye(5); Fw[0, 2] = -2.0
+    np.testing.assert_array_equal(F, Fw)
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_kat9_correction_with_a_heading_on_the_gpu(case, tile, batch):
+    from ekf_slam_amd import Engine
+    x0, xo, Po = (K.K9A_X, K.K9A_X_OUT, K.K9A_P_OUT) if case == "a" else (K.K9B_X, K.K9B_X_OUT, K.K9B_P_OUT)
+    e = Engine(capacity=4, tile=tile, batch=batch)
+    e.set_state(x0, K.K9_P, [1.0])
+    e.correct(K.K9_Z, K.K9_R, 0)
+    np.testing.assert_allclose(e.get_x(), xo, rtol=0, atol=6e-14)
+    np.testing.assert_allclose(e.get_P(), Po, rtol=0, atol=2e-16)
+    e.close()
+
+
+@pytest.mark.parametrize("tile", [16, 128])
+def test_kat10_append_at_heading_90_on_the_gpu(tile):
+    from ekf_slam_amd import Engine
+    a = K.K10_APPEND
+    e = Engine(capacity=4, tile=tile)
+    e.set_state(K.K8_X, K.K8_P, [4.0])
+    e.append(a["u"], a["R"], a["pos"], a["sig"])
+    np.testing.assert_array_equal(e.get_x(), K.K10_X_OUT)
+    np.testing.assert_allclose(e.get_P(), K.K10_P_OUT, rtol=0, atol=4e-15)
+    np.testing.assert_array_equal(e.get_s(), [4.0, 9.0])
+    e.close()
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+def test_kat11_two_corrections_in_a_row_on_the_gpu(tile, batch):
+    """With batch > 1 the second correction reads landmark 2's rows through the first one's PENDING pair."""
+    from ekf_slam_amd import Engine
+    e = Engine(capacity=4, tile=tile, batch=batch)
+    e.set_state(K.K11_X, K.K11_P, [1.0, 2.0])
+    e.correct(K.K11_Z1, K.K11_R1, 0)
+    if batch == 1:
+        np.testing.assert_allclose(e.get_x(), K.K11_X1, rtol=0, atol=5e-16)
+        np.testing.assert_allclose(e.get_P(), K.K11_P1, rtol=0, atol=1e-16)
+    e.correct(K.K11_Z2, K.K11_R2, 1)
+    np.testing.assert_allclose(e.get_x(), K.K11_X2, rtol=0, atol=2e-14)
+    np.testing.assert_allclose(e.get_P(), K.K11_P2, rtol=0, atol=2e-16)
+    e.close()
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+@pytest.mark.parametrize("device_assoc", [0, 1, 2])
+def test_kat12_uc_measure_with_a_new_landmark_on_the_gpu(device_assoc, tile, batch):
+    """EKF_SLAM_UC.measure through the reference-named class: row 1 corrects landmark 1, row 2 matches no signature and is
+    appended with signature N+1 = 3 and the loc of the table entry whose index is 3, row 3 corrects landmark 2 on n = 9."""
+    from ekf_slam_amd.slam import EKF_SLAM_UC
+    for rows, xo, Po, tol in ((2, K.K12_X_AFTER2, K.K12_P_AFTER2, 5e-16), (3, K.K12_X_OUT, K.K12_P_OUT, 2e-14)):
+        h = EKF_SLAM_UC(capacity=4, tile=tile, batch=batch, device_assoc=device_assoc)
+        h.x, h.s, h.P = K.K12_X, K.K12_S, K.K12_P
+        h.measure(None, K.K12_U, K.KatTable(K.K12_TABLE, K.K12_OBSERVED[:rows]))
+        np.testing.assert_allclose(h.x, xo, rtol=0, atol=tol)
+        np.testing.assert_allclose(h.P, Po, rtol=0, atol=2e-13)
+        np.testing.assert_array_equal(h.s, K.K12_S_OUT)
+    # the table entry of index N+1 missing: EKF_ERR_LOOKUP, as the reference's failed comma-list expansion (EKF_SLAM_UC.m:123)
+    from ekf_slam_amd._lib import EkfError, EKF_ERR_LOOKUP
+    h = EKF_SLAM_UC(capacity=4, tile=tile, batch=batch, device_assoc=device_assoc)
+    h.x, h.s, h.P = K.K12_X, K.K12_S, K.K12_P
+    with pytest.raises(EkfError) as ei:
+        h.measure(None, K.K12_U, K.KatTable(K.K12_TABLE[:3], K.K12_OBSERVED))
+    assert ei.value.status == EKF_ERR_LOOKUP

@@ -1,7 +1,8 @@
 """CPU tests of the oracle (test infrastructure): hand-derived known-answer tests from the reference source
 (SURVEY.md section 4, KAT-1..4, and KAT-5..7 for the correction body, append and association -- derivations in
-tests/kat_cases.py; the reference itself holds no golden vectors: PARITY UNPINNED), and literal-dense == structured
-agreement.  The GPU twins of KAT-5..7 are in tests/test_kat_gpu.py."""
+tests/kat_cases.py; the reference itself holds no golden vectors: PARITY UNPINNED), KAT-8..12 at non-zero headings (predict,
+correction, append, two corrections in a row, the UC new-landmark dispatch), and literal-dense == structured
+agreement.  The GPU twins of KAT-5..12 are in tests/test_kat_gpu.py."""
 import numpy as np
 import pytest
 
@@ -150,6 +151,92 @@ def test_kat7_association_costs_by_hand(oracle_lib):
         assert (new, idx) == want, (w_pos, thresh, z)
         np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
         np.testing.assert_array_equal(sc, [(z[2] - 5.0) ** 2] * 2)
+
+
+def _both(mode="known", capacity=8):
+    """The two restatements behind one surface: (name, engine, correct(z, R, idx1))."""
+    d = (D.EKF_SLAM if mode == "known" else D.EKF_SLAM_UC)()
+    st = StructuredEKF(capacity, mode)
+    return [("dense", d, d._correct), ("structured", st, st.correct)]
+
+
+def _load(e, x, P, s):
+    if isinstance(e, StructuredEKF):
+        e.set_state(x, P, s)
+    else:
+        e.x, e.P, e.s = np.array(x, dtype=float), np.array(P, dtype=float), list(s)
+
+
+def test_kat8_predict_at_heading_90_by_hand(oracle_lib):
+    """EKF_SLAM.m:40-51, :56-65 (KAT-8): W and F(1:2,3) with the PRE-motion heading 90, pose with 90 + u2, strip rows move."""
+    for name, e, _ in _both():
+        _load(e, K.K8_X, K.K8_P, [1.0])
+        e.predict(K.K8_U)
+        np.testing.assert_array_equal(e.x, K.K8_X_OUT, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K8_P_OUT, rtol=0, atol=3e-13, err_msg=name)      # 1620.3: one ulp is 2.3e-13
+        np.testing.assert_allclose(np.asarray(e.Q)[:3, :3], K.K8_Q_OUT, rtol=0, atol=3e-13, err_msg=name)
+    x_new, F = D.f(K.K8_X, K.K8_U)                                                           # the public f(x,u), :56-65
+    np.testing.assert_array_equal(x_new, [-1, 2, 180, 3, 4])
+    Fw = np.eye(5); Fw[0, 2] = -2.0; Fw[1, 2] = 0.0
+    np.testing.assert_array_equal(F, Fw)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_kat9_correction_with_a_heading_by_hand(case, oracle_lib):
+    """EKF_SLAM.m:124-145 (KAT-9): z_k = wrapTo360(atan2d(dy,dx) - x(3)) at headings 90 / 270, innovation NOT wrapped."""
+    x0, xo, Po = (K.K9A_X, K.K9A_X_OUT, K.K9A_P_OUT) if case == "a" else (K.K9B_X, K.K9B_X_OUT, K.K9B_P_OUT)
+    for name, e, correct in _both():
+        _load(e, x0, K.K9_P, [1.0])
+        correct(K.K9_Z, K.K9_R, 1)
+        np.testing.assert_allclose(e.x, xo, rtol=0, atol=6e-14, err_msg=name)               # 270 - 4/201: one ulp is 5.7e-14
+        np.testing.assert_allclose(e.P, Po, rtol=0, atol=2e-16, err_msg=name)
+
+
+def test_kat10_append_at_heading_90_by_hand(oracle_lib):
+    """EKF_SLAM.m:67-98 (KAT-10): jxr with the state's heading 90, jz with u2, the old-landmark loop on a non-diagonal P."""
+    a = K.K10_APPEND
+    for name, e, _ in _both():
+        _load(e, K.K8_X, K.K8_P, [4.0])
+        e.append(a["u"], a["R"], a["pos"], a["sig"])
+        np.testing.assert_array_equal(e.x, K.K10_X_OUT, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K10_P_OUT, rtol=0, atol=4e-15, err_msg=name)
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), [4.0, 9.0])
+    x1, P1 = D.append(K.K8_X, K.K8_P, a["u"], 2, a["R"], a["pos"])                          # append.m:1-27, 1 < 2
+    np.testing.assert_allclose(P1, K.K10_P_OUT, rtol=0, atol=4e-15)
+
+
+def test_kat11_two_corrections_in_a_row_by_hand(oracle_lib):
+    """EKF_SLAM.m:107,124-145 (KAT-11): the second correction is linearised at the first one's x+ and P+."""
+    for name, e, correct in _both():
+        _load(e, K.K11_X, K.K11_P, [1.0, 2.0])
+        correct(K.K11_Z1, K.K11_R1, 1)
+        np.testing.assert_allclose(e.x, K.K11_X1, rtol=0, atol=5e-16, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K11_P1, rtol=0, atol=1e-16, err_msg=name)
+        correct(K.K11_Z2, K.K11_R2, 2)
+        np.testing.assert_allclose(e.x, K.K11_X2, rtol=0, atol=2e-14, err_msg=name)         # 102.2: one ulp is 1.4e-14
+        np.testing.assert_allclose(e.P, K.K11_P2, rtol=0, atol=2e-16, err_msg=name)
+
+
+def test_kat12_uc_measure_with_a_new_landmark_by_hand(oracle_lib):
+    """EKF_SLAM_UC.m:102-152 (KAT-12): correction, then a row no signature matches -> append with signature N+1 and the loc of
+    the table entry whose index is N+1, then a correction on the grown state."""
+    for name, e, _ in _both("uc", 8):
+        _load(e, K.K12_X, K.K12_P, K.K12_S)
+        e.measure(None, K.K12_U, K.KatTable(K.K12_TABLE, K.K12_OBSERVED[:2]))
+        np.testing.assert_allclose(e.x, K.K12_X_AFTER2, rtol=0, atol=5e-16, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K12_P_AFTER2, rtol=0, atol=2e-13, err_msg=name)   # 600.25: one ulp is 1.1e-13
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), K.K12_S_OUT)             # signature 3, not the observed 7
+    for name, e, _ in _both("uc", 8):
+        _load(e, K.K12_X, K.K12_P, K.K12_S)
+        e.measure(None, K.K12_U, K.KatTable(K.K12_TABLE, K.K12_OBSERVED))
+        np.testing.assert_allclose(e.x, K.K12_X_OUT, rtol=0, atol=2e-14, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K12_P_OUT, rtol=0, atol=2e-13, err_msg=name)
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), K.K12_S_OUT)
+    # the table entry with index N+1 missing -> the reference's comma-separated-list expansion fails (EKF_SLAM_UC.m:123)
+    d = D.EKF_SLAM_UC()
+    _load(d, K.K12_X, K.K12_P, K.K12_S)
+    with pytest.raises(D.LandmarkLookupError):
+        d.measure(None, K.K12_U, K.KatTable(K.K12_TABLE[:3], K.K12_OBSERVED))
 
 
 @pytest.mark.parametrize("mode", ["known", "uc"])
