@@ -112,13 +112,26 @@ struct ekf_handle {
     static constexpr int kSpecRing = 64;
     AssocHostPartial *h_parts = nullptr, *h_parts_dev = nullptr;
     int64_t parts_stride = 0;
-    bool assoc_poll = true;                    // EKF_ASSOC_POLL=0: wait by stream synchronisation instead of polling the mapped entries
+    bool assoc_poll = true;                    // false (tuning builds, EKF_ASSOC_POLL=0): wait by stream synchronisation instead of polling the mapped entries
     struct Spec { int32_t seq, is_new, nblk; int64_t idx, idx_N; };   // idx_N: landmarks at launch (the default index of a new one)
     std::vector<Spec> spec;
+    // Device-resident measure loop (cfg.device_assoc == 3, the default of EKF_MODE_UC): an observation's association decision is
+    // produced AND consumed on the device (kernels.h: DevLoopArgs); the host queues the launches from its mirror's prediction of
+    // the control flow (append or correct: a function of z(3) and s alone when w_pos == 0) and reads what the device decided
+    // afterwards, from a ring of records in mapped memory -- verified lazily (the next ekf_measure sweeps what has landed;
+    // every call that synchronises or reads state checks the rest first).
+    static constexpr int kLoopRing = 256;
+    AssocHostPartial *d_lparts = nullptr;      // DEVICE: 2 sets of lparts_stride per-workgroup winners
+    int64_t lparts_stride = 0;
+    int32_t loop_set = 0;                      // set written last
+    AssocHostPartial *h_lrec = nullptr, *h_lrec_dev = nullptr;     // MAPPED: kLoopRing decision records
+    struct LoopSpec { int32_t seq, is_new; int64_t idx; };
+    std::vector<LoopSpec> lspec;               // predictions of records lrec_tail .. lrec_head-1 (ring positions mod kLoopRing)
+    uint64_t lrec_head = 0, lrec_tail = 0;
     double *d_pos_cost = nullptr, *d_sig_cost = nullptr, *d_digest = nullptr;
     double *h_small = nullptr;   // pinned 32 doubles
     // sharded correction: exchange slabs (own allocations, or caller-provided device buffers)
-    bool sharded = false;          // world > 1, or forced (EKF_FORCE_SHARDED=1) to exercise the path on one GPU
+    bool sharded = false;          // world > 1, or cfg.force_sharded (the sharded code path with one rank, on one GPU)
     double *own_send = nullptr, *own_recv = nullptr, *send = nullptr, *recv = nullptr;
     int64_t slab_cap = 0;          // doubles per shard slab at capacity
     int64_t xchg_cap = 0;          // doubles of the send area (the receive area holds world times as many)
@@ -203,7 +216,7 @@ int32_t refresh_work(ekf_handle *h) {
     h->work_rows = nt;
 
     // per-XCD streams: super-tiles of S x S tiles, largest first onto the least loaded stream
-    static const int S = [] { const char *v = getenv("EKF_SUPERTILE"); const int x = v ? atoi(v) : 8; return x < 1 ? 1 : x; }();
+    static const int S = std::max(1, ekf_tune_int("EKF_SUPERTILE", 8));
     struct Super { int64_t si, sj; std::vector<int2> tiles; };
     std::vector<Super> supers;
     const int64_t ns = (nt + S - 1) / S;
@@ -220,7 +233,7 @@ int32_t refresh_work(ekf_handle *h) {
     // its L2 for the whole band and only the G slice changes from one super-tile to the next; runs are equal to within one tile.
     // 0: round 1's schedule (largest super-tile first onto the least loaded stream): every super-tile fetched both slices anew
     // and the streams differed by up to a super-tile (profiles/round2_tuning.md).
-    static const int order = [] { const char *v = getenv("EKF_XCD_ORDER"); return v ? atoi(v) : 1; }();
+    static const int order = ekf_tune_int("EKF_XCD_ORDER", 1);
     std::vector<int2> stream[8];
     if (order == 0) {
         std::stable_sort(supers.begin(), supers.end(), [](const Super &a, const Super &b) { return a.tiles.size() > b.tiles.size(); });
@@ -290,9 +303,9 @@ int32_t retire_inflight(ekf_handle *h) {
 // Every other pass over P walks its work list backwards (TileMap::reverse, read by the pass kernels only): what one pass wrote
 // last the next one reads first, out of the Infinity Cache -- 4 % off the pass at 10 k landmarks (1.6 GB of tiles), 10 % at
 // 5 k (400 MB).  A store that fits the cache whole is resident either way and measured 1.5 % faster walked forwards, so the
-// direction only alternates above kCacheBytes.  EKF_PASS_ALTERNATE=0 / 1 forces never / always.
+// direction only alternates above kCacheBytes.  cfg.pass_direction = 1 / 2 forces never / always.
 void next_pass_direction(ekf_handle *h) {
-    static const int force = [] { const char *v = getenv("EKF_PASS_ALTERNATE"); return v ? atoi(v) : -1; }();
+    const int force = h->cfg.pass_direction == 1 ? 0 : h->cfg.pass_direction == 2 ? 1 : -1;
     constexpr int64_t kCacheBytes = 256ll << 20;
     const int64_t nt = ekf_tiles_for(n_mm(h), h->T);
     const int64_t store = nt * (nt + 1) / 2 / std::max(1, h->cfg.world) * (int64_t)h->T * h->T * (h->storage == EKF_STORE_F64 ? 8 : 4);
@@ -359,6 +372,55 @@ int32_t batch_complete(ekf_handle *h) {
     return EKF_OK;
 }
 
+// one snapshot of a self-validating 16-byte entry (kernels.h: AssocHostPartial): payload, and the launch number its tag stands
+// for GIVEN that payload
+struct PartView { double ll; int32_t index; int32_t seq; };
+inline PartView read_part(const volatile AssocHostPartial *e) {
+    const volatile uint64_t *w = reinterpret_cast<const volatile uint64_t *>(e);
+    const uint64_t lo = w[0], hi = w[1];
+    PartView v;
+    memcpy(&v.ll, &lo, 8);
+    v.index = (int32_t)(uint32_t)(hi & 0xffffffffu);
+    v.seq = (int32_t)((uint32_t)(hi >> 32) - assoc_part_mix((uint32_t)(lo & 0xffffffffu), (uint32_t)(lo >> 32), (uint32_t)v.index));
+    return v;
+}
+
+// Device-resident measure loop: compare what the device decided (records in mapped memory) with what the host predicted when it
+// queued the launches.  block == false: only the records that have landed; block == true: all of them (the stream is synchronised
+// if the newest has not landed within the polling bound).
+int32_t verify_loop(ekf_handle *h, bool block) {
+    if (h->lrec_tail == h->lrec_head) return EKF_OK;
+    if (block) {
+        const volatile AssocHostPartial *newest = h->h_lrec + (h->lrec_head - 1) % ekf_handle::kLoopRing;
+        const int32_t want = h->lspec.back().seq;
+        bool landed = false;
+        for (int spin = 0; spin < 200000 && !landed; ++spin) { landed = read_part(newest).seq == want; if (!landed) __builtin_ia32_pause(); }
+        if (!landed) HIPCHK(h, hipStreamSynchronize(h->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    size_t done = 0;
+    int32_t rc = EKF_OK;
+    for (; h->lrec_tail < h->lrec_head; ++h->lrec_tail, ++done) {
+        const ekf_handle::LoopSpec &sp = h->lspec[done];
+        const PartView v = read_part(h->h_lrec + h->lrec_tail % ekf_handle::kLoopRing);
+        if (v.seq != sp.seq) {
+            if (!block) break;                                          // not there yet (records land in stream order)
+            rc = fail(h, EKF_ERR_STATE, "measure: a decision record of the device-resident loop is missing");
+            continue;
+        }
+        const bool same = sp.is_new ? v.index == -1 : (int64_t)v.index == sp.idx;
+        if (!same) {
+            char buf[200];
+            snprintf(buf, sizeof buf, "measure: the device association decided %s %d where the host mirror of the signatures "
+                     "predicted %s %lld; the state is no longer the reference's", v.index == -1 ? "new landmark" : v.index == -2 ?
+                     "(stale winner entries)" : "landmark", (int)v.index, sp.is_new ? "new landmark" : "landmark", (long long)sp.idx);
+            rc = fail(h, EKF_ERR_STATE, buf);
+        }
+    }
+    h->lspec.erase(h->lspec.begin(), h->lspec.begin() + (ptrdiff_t)done);
+    return rc;
+}
+
 int32_t materialize_predict(ekf_handle *h) {
     if (!h->have_pp) return EKF_OK;
     h->have_pp = false;
@@ -377,17 +439,20 @@ int32_t do_predict(ekf_handle *h, const double u[2]) {
     if (rc) return rc;
     h->pp.u0 = u[0]; h->pp.u1 = u[1]; h->pp.C = h->cfg.C; h->pp.n_mm = 0; h->pp.cur = 0;
     h->have_pp = true;
-    static const bool lazy = [] { const char *v = getenv("EKF_LAZY_PREDICT"); return !v || atoi(v) != 0; }();
+    static const bool lazy = ekf_tune_int("EKF_LAZY_PREDICT", 1) != 0;
     return lazy ? EKF_OK : materialize_predict(h);
 }
 
 // device + every deferred host-side decision that the caller's next read depends on
 int32_t enter(ekf_handle *h) {
     HIPCHK(h, hipSetDevice(h->cfg.device));
+    const int32_t rc = verify_loop(h, /*block*/ true);
+    if (rc) return rc;
     return materialize_predict(h);
 }
 
-int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature) {
+int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature,
+                  const DevLoopArgs *dl = nullptr) {
     REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
     {
         int32_t rcp = materialize_predict(h);
@@ -401,7 +466,7 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     a.pos0 = pos[0]; a.pos1 = pos[1]; a.signature = signature; a.N = h->N; a.cur = h->cur;
     {
         TimedLaunch tl(h, EKF_KERNEL_APPEND);
-        HIPCHK(h, launch_append(h->st, a, h->storage, h->stream));
+        HIPCHK(h, launch_append(h->st, a, h->storage, h->stream, dl));
     }
     if ((int64_t)h->s_host.size() > h->N) h->s_host.resize((size_t)h->N);
     h->s_host.push_back(signature);
@@ -543,8 +608,8 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     CorrectArgs a;
     fill_correct_args(h, a, z, R, idx);
     // small maps (one workgroup covers every column), every correction rewriting P at once: the downdate runs inside the gather
-    // kernel -- one launch per update-step instead of two (EKF_FUSE_SMALL=0: always two)
-    static const bool fuse_small = [] { const char *v = getenv("EKF_FUSE_SMALL"); return !v || atoi(v) != 0; }();
+    // kernel -- one launch per update-step instead of two
+    static const bool fuse_small = ekf_tune_int("EKF_FUSE_SMALL", 1) != 0;
     const bool fused = fuse_small && h->batch == 1 && !h->async_flush && h->npend == 0 && a.n_mm <= gather_fuse_max_rows() &&
                        ekf_tiles_for(a.n_mm, h->T) * h->T <= 256;
     {
@@ -558,6 +623,23 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
         snprintf(h->dd_kernel, sizeof h->dd_kernel, "k_gather<%s,fused downdate>", h->storage == EKF_STORE_F64 ? "double" : "float");
         h->dd_pairs = 1;
         return throttle_step(h);
+    }
+    return finish_step(h);
+}
+
+// device-resident measure loop: the correction of the landmark the DEVICE's association names (dl.parts_in); idx, the host
+// mirror's prediction, only keeps a launch whose winners name nothing inside the state.  Never the small-map fused form.
+int32_t do_correct_dev(ekf_handle *h, const double z[2], const double R[4], int64_t idx, const DevLoopArgs &dl) {
+    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INDEX, "correct: landmark index outside the state");
+    int32_t rc = refresh_work(h);
+    if (rc) return rc;
+    CorrectArgs a;
+    fill_correct_args(h, a, z, R, idx);
+    {
+        TimedLaunch tl(h, EKF_KERNEL_GATHER);
+        const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+        HIPCHK(h, launch_gather_devloop(h->st, a, fuse, dl, h->storage, h->stream));
+        h->have_pp = false;
     }
     return finish_step(h);
 }
@@ -576,18 +658,6 @@ bool wait_mapped_seq(volatile AssocDecision *slot, int32_t seq) {
 }
 
 inline int32_t assoc_blocks(int64_t N) { return (int32_t)((N + kAssocBlock - 1) / kAssocBlock); }
-
-// one snapshot of a mapped entry: payload, and the launch sequence number its tag stands for GIVEN that payload
-struct PartView { double ll; int32_t index; int32_t seq; };
-inline PartView read_part(const volatile AssocHostPartial *e) {
-    const volatile uint64_t *w = reinterpret_cast<const volatile uint64_t *>(e);
-    const uint64_t lo = w[0], hi = w[1];
-    PartView v;
-    memcpy(&v.ll, &lo, 8);
-    v.index = (int32_t)(uint32_t)(hi & 0xffffffffu);
-    v.seq = (int32_t)((uint32_t)(hi >> 32) - assoc_part_mix((uint32_t)(lo & 0xffffffffu), (uint32_t)(lo >> 32), (uint32_t)v.index));
-    return v;
-}
 
 // all nblk workgroups of launch `seq` have stored their winner (self-validating entries: kernels.h)
 bool wait_parts(volatile AssocHostPartial *set, int32_t nblk, int32_t seq) {
@@ -809,7 +879,7 @@ int32_t ekf_config_default(ekf_config *cfg, int32_t mode) {
     cfg->world = 1;
     cfg->batch = 1;
     cfg->async_flush = 0;
-    cfg->device_assoc = 0;
+    cfg->device_assoc = mode == EKF_MODE_UC ? 3 : 0;   // unknown correspondence: the association runs, and is consumed, on the device
     return EKF_OK;
 }
 
@@ -873,9 +943,8 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
                 // workgroup slots -- measured 20 us per gather, stream priorities do not help (profiles/round1_tuning.md, sweep
                 // 12).  So the flush stream is confined to a CU mask that leaves `reserve` CUs (default 32 = 4 per XCD) to the
                 // gather chain.  Reserved set {32a + 8b + a}: 4 CUs on every XCD whether mask bits map to XCDs round-robin
-                // (bit % 8) or in blocks of 32.  EKF_ASYNC_RESERVE_CUS=0: plain lowest-priority stream.
-                const char *rv = getenv("EKF_ASYNC_RESERVE_CUS");
-                int reserve = rv ? atoi(rv) : 32;
+                // (bit % 8) or in blocks of 32.  (Tuning builds: EKF_ASYNC_RESERVE_CUS=0 gives a plain lowest-priority stream.)
+                int reserve = ekf_tune_int("EKF_ASYNC_RESERVE_CUS", 32);
                 hipDeviceProp_t prop;
                 HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
                 const int ncu = prop.multiProcessorCount;
@@ -918,8 +987,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->d_sig_cost, (size_t)h->cap));
     HIPCHK(h, dalloc(h, &h->d_digest, kDigestDoubles));
     {
-        const char *fs = getenv("EKF_FORCE_SHARDED");
-        h->sharded = world > 1 || (fs && atoi(fs) != 0);
+        h->sharded = world > 1 || cfg->force_sharded != 0;
         if (h->sharded) {
             h->slab_cap = slab_for(h, 2 * h->cap);
             const size_t rows = (size_t)(cfg->batch < 1 ? 1 : cfg->batch);     // a prefetch carries up to `batch` row-panels
@@ -935,14 +1003,14 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, hipHostMalloc((void **)&h->h_decision, sizeof(AssocDecision), hipHostMallocMapped));
     memset(h->h_decision, 0, sizeof(AssocDecision));
     {
-        static const bool poll = [] { const char *v = getenv("EKF_ASSOC_POLL"); return !v || atoi(v) != 0; }();
+        static const bool poll = ekf_tune_int("EKF_ASSOC_POLL", 1) != 0;
         void *dp = nullptr;
         if (poll && hipHostGetDevicePointer(&dp, h->h_decision, 0) == hipSuccess) h->h_decision_dev = (AssocDecision *)dp;
     }
     {
         // k_associate's per-workgroup winners (see ekf_handle::h_parts): kSpecRing sets for cfg.device_assoc == 2, one more for
         // the calls that wait; 16 bytes per workgroup at capacity
-        static const bool poll = [] { const char *v = getenv("EKF_ASSOC_POLL"); return !v || atoi(v) != 0; }();
+        static const bool poll = ekf_tune_int("EKF_ASSOC_POLL", 1) != 0;
         h->assoc_poll = poll;
         h->parts_stride = assoc_blocks(h->cap > 0 ? h->cap : 1);
         const size_t bytes = sizeof(AssocHostPartial) * (size_t)h->parts_stride * (ekf_handle::kSpecRing + 1);
@@ -954,6 +1022,19 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_parts, 0));
         h->h_parts_dev = (AssocHostPartial *)dp;
     }
+    {
+        // device-resident measure loop: two sets of per-workgroup winners (a k_associate launch has ceil(N / 256) workgroups, a
+        // k_gather launch one per 256 padded columns) and the ring of decision records
+        h->lparts_stride = std::max<int64_t>(assoc_blocks(h->cap), gather_workgroups(h->st, 2 * h->cap));
+        HIPCHK(h, dalloc(h, &h->d_lparts, (size_t)(2 * h->lparts_stride)));
+        const size_t bytes = sizeof(AssocHostPartial) * ekf_handle::kLoopRing;
+        HIPCHK(h, hipHostMalloc((void **)&h->h_lrec, bytes, hipHostMallocMapped));
+        memset(h->h_lrec, 0, bytes);
+        for (int e = 0; e < ekf_handle::kLoopRing; ++e) h->h_lrec[e].tag = (int32_t)assoc_part_mix(0, 0, 0);   // reads as launch 0
+        void *dp = nullptr;
+        HIPCHK(h, hipHostGetDevicePointer(&dp, h->h_lrec, 0));
+        h->h_lrec_dev = (AssocHostPartial *)dp;
+    }
     HIPCHK(h, hipHostMalloc((void **)&h->h_small, 32 * sizeof(double), hipHostMallocDefault));
 
     // x = [0 0 0]; P = 0.1*eye(3)   (EKF_SLAM.m:28-31, EKF_SLAM_UC.m:29-32)
@@ -961,8 +1042,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, hipMemcpy(h->st.prr[0], prr0, sizeof prr0, hipMemcpyHostToDevice));
     h->cur = 0;
     h->N = 0;
-    const char *gc = getenv("EKF_DOWNDATE_GRID");
-    h->grid_cap = gc ? atoi(gc) : 0;
+    h->grid_cap = ekf_tune_int("EKF_DOWNDATE_GRID", 0);
     HIPCHK(h, hipDeviceSynchronize());
     return EKF_OK;
 }
@@ -981,6 +1061,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);
     if (h->h_parts) hipHostFree(h->h_parts);
+    if (h->h_lrec) hipHostFree(h->h_lrec);
     if (h->h_small) hipHostFree(h->h_small);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -1100,6 +1181,19 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
             if (rc) return rc;
         }
     }
+    // cfg.device_assoc == 3 (the default of EKF_MODE_UC): the device-resident loop.  Per observation the host queues
+    //   [k_associate, only if the previous launch did not already evaluate this observation's association]  ->
+    //   k_gather (takes the landmark from the device's decision; its epilogue evaluates the NEXT observation's association)
+    //   or k_append (checks the device found nothing below the threshold)  ->  the pass over P when a batch is complete
+    // with no wait anywhere: which of the two it queues is the host mirror's prediction (exact when w_pos == 0: the reference's
+    // live likelihood is a function of z(3) and s alone, Correspondence.m:71,75), what the device decided comes back in records
+    // that are checked later (verify_loop).  With w_pos != 0 the host cannot predict the branch: the waited path below.
+    const bool dev_loop = h->cfg.mode == EKF_MODE_UC && h->cfg.device_assoc == 3 && h->cfg.w_pos == 0.0 && !h->sharded;
+    struct { bool have; int set; int32_t seq, nblk; } nxt = { false, 0, 0, 0 };     // winners of row ii's association already on the device
+    if (dev_loop) {
+        rc = verify_loop(h, /*block*/ false);                              // what earlier scans' launches have reported by now
+        if (rc) return rc;
+    }
     for (int64_t ii = 0; ii < m; ++ii) {                                   // EKF_SLAM.m:107
         const double z[3] = { obs[ii], obs[m + ii], obs[2 * m + ii] };
         const double R[4] = { z[0] * h->cfg.Rc[0], 0.0, 0.0, z[1] * h->cfg.Rc[1] };   // :108
@@ -1116,11 +1210,47 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
             } else {
                 rc = do_correct(h, z, R, ii);                              // :123  idx = ii
             }
+        } else if (dev_loop) {
+            int32_t is_new = 0;
+            int64_t idx = 0;
+            associate_signature_only(h, z[2], &is_new, &idx);              // the prediction that shapes the queue
+            DevLoopArgs dl = {};
+            if (!nxt.have) {                                               // EKF_SLAM_UC.m:119, as a launch of its own
+                nxt.set = h->loop_set ^ 1; nxt.seq = next_assoc_seq(h); nxt.nblk = assoc_blocks(h->N);
+                rc = launch_assoc(h, z, R, h->d_lparts + (int64_t)nxt.set * h->lparts_stride, nxt.seq);
+                if (rc) return rc;
+                h->loop_set = nxt.set;
+            }
+            dl.parts_in = h->d_lparts + (int64_t)nxt.set * h->lparts_stride; dl.nblk_in = nxt.nblk; dl.seq_in = nxt.seq;
+            if (h->lrec_head - h->lrec_tail >= (uint64_t)ekf_handle::kLoopRing) { rc = verify_loop(h, /*block*/ true); if (rc) return rc; }
+            dl.rec = h->h_lrec_dev + h->lrec_head % ekf_handle::kLoopRing;
+            dl.seq_rec = next_assoc_seq(h);
+            const int set_in = nxt.set;
+            nxt.have = false;
+            if (is_new) {                                                  // EKF_SLAM_UC.m:121-123
+                rc = lookup_loc(h, lm_index, lm_loc, L, false, (double)(idx + 1), loc);
+                if (rc) return rc;
+                rc = do_append(h, u, R, loc, (double)(idx + 1), &dl);
+            } else {
+                if (ii + 1 < m) {                                          // the next row's association rides in this correction
+                    const double zn[3] = { obs[ii + 1], obs[m + ii + 1], obs[2 * m + ii + 1] };
+                    dl.parts_out = h->d_lparts + (int64_t)(set_in ^ 1) * h->lparts_stride;
+                    dl.seq_out = next_assoc_seq(h);
+                    dl.z0 = zn[0]; dl.z1 = zn[1]; dl.z2 = zn[2];
+                    dl.R00 = zn[0] * h->cfg.Rc[0]; dl.R01 = 0.0; dl.R10 = 0.0; dl.R11 = zn[1] * h->cfg.Rc[1];   // :108 / UC :110
+                    dl.s_cost = h->cfg.s_cost; dl.s_thresh = h->cfg.s_thresh; dl.w_pos = h->cfg.w_pos;
+                    nxt.have = true; nxt.set = set_in ^ 1; nxt.seq = dl.seq_out; nxt.nblk = (int32_t)gather_workgroups(h->st, n_mm(h));
+                }
+                rc = do_correct_dev(h, z, R, idx, dl);
+                if (!rc && nxt.have) h->loop_set = nxt.set;
+            }
+            if (rc) return rc;
+            h->lspec.push_back({ dl.seq_rec, is_new, idx });
+            ++h->lrec_head;
         } else {
             int32_t is_new = 0;
             int64_t idx = 0;
-            static const bool force_dev = [] { const char *v = getenv("EKF_FORCE_DEVICE_ASSOC"); return v && atoi(v) != 0; }();
-            if (h->cfg.w_pos == 0.0 && !force_dev && h->cfg.device_assoc != 1) {
+            if (h->cfg.w_pos == 0.0 && h->cfg.device_assoc != 1) {
                 // The reference's decision is a pure function of z(3) and s: the Mahalanobis position cost it also
                 // evaluates is discarded (Correspondence.m:74-75).  With w_pos == 0 measure() therefore decides from
                 // the host mirror of s -- same arithmetic as k_associate, no launch, no device->host sync.

@@ -5,6 +5,16 @@
 
 #include "layout.h"
 
+// Tuning switches.  The PRODUCT library compiles every one of them to its default constant: no environment variable changes
+// which kernel a handle runs.  Only a -DEKF_TUNING build (make -C ekf_slam_amd/csrc tuning -> libekfslam_tuning.so, used by
+// scripts/ab_*.sh and scripts/tune_*.py through EKF_LIB_PATH) reads them from the environment.
+#ifdef EKF_TUNING
+#include <stdlib.h>
+inline int ekf_tune_int(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+constexpr int ekf_tune_int(const char *, int dflt) { return dflt; }
+#endif
+
 // Device-resident filter state.  Passed BY VALUE to every kernel.
 //   x / prr / strip are double-buffered: every kernel reads buffer `cur` and writes a complete buffer
 //   `cur ^ 1`, so no workgroup ever reads a value another workgroup of the same launch overwrites.
@@ -89,16 +99,39 @@ inline uint32_t assoc_part_mix(uint32_t ll_lo, uint32_t ll_hi, uint32_t index) {
     return m;
 }
 
+// Device-resident measure() loop (EKF_SLAM_UC.m:107-151 without a host round trip per observation): the association decision of
+// an observation is PRODUCED on the device (k_associate, or the epilogue of the previous observation's k_gather) as one winner per
+// workgroup, and CONSUMED on the device by the next launch (k_gather takes its landmark from the arg-min over those winners;
+// k_append checks that nothing passed the threshold).  The host only learns the decisions afterwards, from `rec`.
+struct DevLoopArgs {
+    const AssocHostPartial *parts_in;   // DEVICE: per-workgroup winners of THIS observation's association; nullptr: not in use
+    AssocHostPartial *rec;              // MAPPED HOST: the decision this launch consumed, one self-validating 16-byte store
+                                        //   (index: landmark 0-based, -1 = new landmark, -2 = a winner entry did not carry seq_in)
+    AssocHostPartial *parts_out;        // DEVICE: winners of the NEXT observation's association, evaluated in k_gather's epilogue
+                                        //   on the state this correction leaves (one entry per k_gather workgroup); nullptr: none
+    int32_t nblk_in, seq_in;            // entries of parts_in and the launch number they must carry
+    int32_t seq_rec, seq_out;           // launch numbers stamped on rec / parts_out
+    double z0, z1, z2;                  // the next observation [range, bearing_deg, signature] and its R
+    double R00, R01, R10, R11;
+    double s_cost, s_thresh, w_pos;
+};
+
 constexpr int kAssocBlock = 256;       // 4 wavefronts = one per SIMD: the per-landmark solve is a dependent f64 chain (1024 measured slower: 16 wavefronts share one CU's f64 issue)
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
-hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s);
+// dl != nullptr (device-resident measure loop): the kernel also reduces dl->parts_in and records the decision in dl->rec
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dl = nullptr);
 // fused_predict != nullptr folds predict(u) into the correction (one launch instead of two, identical arithmetic)
 // fuse_downdate: the kernel also applies its pair to the landmark block (small maps: a.n_mm <= gather_fuse_max_rows(), one
 // workgroup); the pair is then NOT written to the pending ring and no downdate launch must follow
 hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, int storage,
                          hipStream_t s, bool fuse_downdate);
 int gather_fuse_max_rows();
+// device-resident measure loop: the corrected landmark is the arg-min over dl.parts_in (a.j is the fallback that keeps a launch
+// whose winners name no landmark inside the state); dl.parts_out != nullptr adds the next observation's association
+hipError_t launch_gather_devloop(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const DevLoopArgs &dl,
+                                 int storage, hipStream_t s);
+int64_t gather_workgroups(const DevState &st, int64_t n_mm);
 // sharded correction: (1) every shard copies the chunks of the landmark row-panel P(j:j+1,:) it owns into `send`
 // (slab layout: local chunk kl of T columns, interleaved pairs), (2) the slabs are all-gathered into `recv`
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.

@@ -250,11 +250,75 @@ __global__ __launch_bounds__(kBlock) void k_predict_mfma(DevState st, PredictArg
 }
 
 // ---------------------------------------------------------------------------------------------------
+// association order and the per-workgroup winner entries (used by k_associate, and by the kernels of the device-resident
+// measure loop that consume a decision: k_gather, k_append)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool assoc_better(double la, int64_t ia, double lb, int64_t ib) {
+    // strict '<' on the likelihood, first (lowest) index wins ties (Correspondence.m:81)
+    return la < lb || (la == lb && ia < ib);
+}
+
+// arg-min over a wavefront under assoc_better's order (a total order: every lane ends with the same winner)
+__device__ __forceinline__ void wave_argmin(double &ll, int64_t &ix) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ol = __shfl_xor(ll, off);
+        const int64_t oi = __shfl_xor((long long)ix, off);
+        if (assoc_better(ol, oi, ll, ix)) { ll = ol; ix = oi; }
+    }
+}
+
+// One self-validating 16-byte entry (kernels.h: AssocHostPartial): payload and launch number in ONE store instruction.
+__device__ __forceinline__ void store_partial(AssocHostPartial *dst, double ll, int index, int seq) {
+    typedef int part_v4 __attribute__((ext_vector_type(4)));
+    part_v4 v;
+    const long long lb = __double_as_longlong(ll);
+    v.x = (int)(lb & 0xffffffffll); v.y = (int)(lb >> 32);
+    v.z = index;
+    v.w = (int)((uint32_t)seq + assoc_part_mix((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z));
+    *reinterpret_cast<part_v4 *>(dst) = v;
+}
+
+// Correspondence.m:78-85 over the per-workgroup winners of one association launch (lowest likelihood, lowest index on ties --
+// the order of the kernel's own reductions), by ONE wavefront; every lane returns the same (ll, ix):
+// ix >= 0 the matched landmark, -1 nothing passed the threshold (new landmark), -2 an entry does not carry launch number `seq`.
+__device__ __forceinline__ void reduce_partials_wave(const AssocHostPartial *__restrict__ parts, int nblk, int seq, int lane,
+                                                     double &ll, int &ix) {
+    typedef int part_v4 __attribute__((ext_vector_type(4)));
+    double bl = INFINITY;
+    int64_t bi = INT64_MAX;
+    int bad = 0;
+    for (int b = lane; b < nblk; b += 64) {
+        const part_v4 v = *reinterpret_cast<const part_v4 *>(parts + b);
+        const int got = (int)((uint32_t)v.w - assoc_part_mix((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z));
+        const double pl = __longlong_as_double(((long long)v.y << 32) | (long long)(uint32_t)v.x);
+        if (got != seq) bad = 1;
+        else if (v.z >= 0 && assoc_better(pl, (int64_t)v.z, bl, bi)) { bl = pl; bi = v.z; }
+    }
+    wave_argmin(bl, bi);
+    bad = __any(bad);
+    ll = bl;
+    ix = bad ? -2 : (bi == INT64_MAX ? -1 : (int)bi);
+}
+
+struct NoDevLoop {};
+template <bool kDev> struct DevLoopParam { using type = NoDevLoop; };
+template <> struct DevLoopParam<true> { using type = DevLoopArgs; };
+
+// ---------------------------------------------------------------------------------------------------
 // append: in place on buffer `cur` (only new slots are written)
 // ---------------------------------------------------------------------------------------------------
 template <typename TS>
-__global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a) {
+__global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, DevLoopArgs dl) {
     const int cur = a.cur;
+    if (dl.parts_in != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+        // device-resident measure loop: the association of this observation must have found nothing below the threshold
+        // (EKF_SLAM_UC.m:121); what it did find goes to the host's record
+        double dll;
+        int dix;
+        reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, (int)threadIdx.x, dll, dix);
+        if (threadIdx.x == 0) store_partial(dl.rec, dll, dix, dl.seq_rec);
+    }
     double *__restrict__ x = st.x[cur];
     double *__restrict__ s = st.strip[cur];
     const double *__restrict__ prr = st.prr[cur];
@@ -521,8 +585,16 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 constexpr int kFuseMaxRows = 48;                     // landmark-block rows (24 landmarks) up to which the fused form is used (beyond: slower than two launches)
 constexpr int kFuseElems = kFuseMaxRows * kFuseMaxRows / 256;     // elements of the block per column lane, all in flight together
 
-template <typename TS, bool kSharded, bool kPredict, bool kFused = false>
-__global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa) {
+// kDev (device-resident measure loop, unsharded): the corrected landmark is not a kernel argument but the arg-min over the
+// per-workgroup winners of this observation's association (dl.parts_in), reduced redundantly by every wavefront; and the NEXT
+// observation's association (Correspondence.m:49-87: per-landmark phi_k, Mahalanobis + signature cost, thresholded arg-min) is
+// evaluated in the epilogue by the column lanes, from the values this correction has just produced -- x', strip', Prr', the
+// landmark's own 2x2 block patched with the pending pairs and this correction's pair -- with the per-entry functions k_associate
+// uses: one launch per observation instead of two.
+template <typename TS, bool kSharded, bool kPredict, bool kFused = false, bool kDev = false>
+__global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa,
+                                                         typename DevLoopParam<kDev>::type dl) {
+    static_assert(!kDev || (!kSharded && !kFused), "the device loop drives the plain unsharded gather");
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
     __shared__ PredictSmall ps;
@@ -545,8 +617,19 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     double *__restrict__ strip_nxt = cur ? st.strip[0] : st.strip[1];
     double *__restrict__ prr_nxt = cur ? st.prr[0] : st.prr[1];
     const TS *__restrict__ tiles = (const TS *)st.tiles;
-    const int64_t j = a.j, ldm = st.ldm;
+    int64_t j = a.j;
+    const int64_t ldm = st.ldm;
     const int npend = a.npend, pstart = a.pstart;
+    if constexpr (kDev) {
+        // EKF_SLAM_UC.m:119-125: idx comes from the association, on the device.  Every wavefront reduces the winners itself
+        // (<= 64 entries: one 16-byte load per lane + a butterfly) -- no LDS, no barrier in front of the j-dependent loads.
+        double dll;
+        int dix;
+        reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, lane, dll, dix);
+        dix = __builtin_amdgcn_readfirstlane(dix);
+        if (dix >= 0 && 2 * (int64_t)dix < a.n_mm) j = 2 * (int64_t)dix;       // otherwise a.j: the launch stays inside the state
+        if (blockIdx.x == 0 && tid == kGatherCols + 128) store_partial(dl.rec, dll, dix, dl.seq_rec);   // BEARING lane 0: it has slack
+    }
 
     // Fetch every kernel argument this kernel uses NOW, in one burst of scalar loads: left to itself the compiler fetches
     // them lazily, right before their first use, which put three dependent round trips to the argument block at the head of
@@ -957,6 +1040,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     double2 *__restrict__ Gout = reinterpret_cast<double2 *>(st.Gp + out_off);
     double2 *__restrict__ Kout = reinterpret_cast<double2 *>(st.Kp + out_off);
     double g[2] = { 0.0, 0.0 }, k0 = 0.0, k1 = 0.0;
+    double xn = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0;               // x'(c), strip'(0..2, c): stored, and read again by the kDev epilogue
     if (live) {
         if (kPredict) predict_strip(s0, s1, s2, ps.fa, ps.fb);
         for (int r = 0; r < 2; ++r)
@@ -967,11 +1051,15 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             Gout[c] = make_double2(g[0], g[1]);
             Kout[c] = make_double2(k0, k1);
         }
-        x_nxt[3 + c] = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
+        xn = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
+        t0 = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
+        t1 = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
+        t2 = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
+        x_nxt[3 + c] = xn;
         double *__restrict__ sn = strip_nxt;
-        sn[c] = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
-        sn[ldm + c] = s1 - (sol.Kr[1][0] * g[0] + sol.Kr[1][1] * g[1]);
-        sn[2 * ldm + c] = s2 - (sol.Kr[2][0] * g[0] + sol.Kr[2][1] * g[1]);
+        sn[c] = t0;
+        sn[ldm + c] = t1;
+        sn[2 * ldm + c] = t2;
     } else if (c < pad_end && !kFused) {
         // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
         Gout[c] = make_double2(0.0, 0.0);
@@ -1007,6 +1095,88 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
 #pragma unroll
             for (int q = 0; q < kFuseElems; ++q)
                 if (ptr[q]) *ptr[q] = (TS)rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]);
+        }
+    }
+    if constexpr (kDev) {
+        if (dl.parts_out != nullptr) {                            // uniform
+            // ---- the NEXT observation's association (Correspondence.m:49-87) on the state this correction leaves.  Landmark
+            //      k = c / 2 is scored by its even column lane; everything it needs is in this lane pair's registers (x', strip',
+            //      this correction's K(c,:), G(:,c)) or in the workgroup's LDS (Prr before the correction, K_r, G_r, nu) -- except
+            //      the base value of its own 2x2 block and the pending pairs' operands at its columns (L2-resident).
+            __shared__ double na_ll[kGatherCols / 64];
+            __shared__ int na_ix[kGatherCols / 64];
+            const bool odd = (c & 1) != 0;
+            const int64_t cl = live ? c : (c & 1);                // clamped: unconditional loads, no shuffles under divergence
+            // own diagonal entry and, on odd columns, the one left of it: canonical (2k,2k) | (2k+1,2k), (2k+1,2k+1) ...
+            double dcc = 0.0, dlo = 0.0;
+            if (odd) pmm_low_pair<TS>(tiles, st.tm, cl, cl - 1, dlo, dcc);
+            else dcc = pmm_low<TS>(tiles, st.tm, cl, cl);
+            // ... minus the pending pairs in slot order (pmm_live's chain, as k_associate runs it), 8 pairs' operands in flight together
+            {
+                const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + cl;
+                const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + cl;
+                for (int i0 = 0; i0 < npend; i0 += 8) {
+                    double2 kk[8], gg[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int64_t so = (int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2;
+                        kk[q] = kp[so]; gg[q] = gp[so];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const double2 gl = make_double2(__shfl_xor(gg[q].x, 1), __shfl_xor(gg[q].y, 1));   // the partner column's G_i
+                        if (i0 + q < npend) {
+                            dcc = rank2_apply(dcc, kk[q], gg[q]);
+                            dlo = rank2_apply(dlo, kk[q], gl);    // odd lanes: K_i(2k+1,:) G_i(:,2k)
+                        }
+                    }
+                }
+                // ... and this correction's own pair (ring position npend), from registers
+                const double2 kn = make_double2(k0, k1), gn = make_double2(g[0], g[1]);
+                const double2 gl = make_double2(__shfl_xor(gn.x, 1), __shfl_xor(gn.y, 1));
+                dcc = rank2_apply(dcc, kn, gn);
+                dlo = rank2_apply(dlo, kn, gl);
+            }
+            // odd lane -> even lane
+            const double xn_o = __shfl_xor(xn, 1), t0_o = __shfl_xor(t0, 1), t1_o = __shfl_xor(t1, 1), t2_o = __shfl_xor(t2, 1),
+                         d10 = __shfl_xor(dlo, 1), d11 = __shfl_xor(dcc, 1);
+            double ll = INFINITY;
+            int64_t ix = INT64_MAX;
+            if (live && !odd) {
+                const int64_t k = c >> 1;
+                double q[24];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b)                   // Prr' as the DIAG wavefront stores it
+                        q[3 * r + b] = pss[3 * r + b] - (sol.Kr[r][0] * sol.Gr[0][b] + sol.Kr[r][1] * sol.Gr[1][b]);
+                q[9] = t0; q[10] = t0_o; q[11] = t1; q[12] = t1_o; q[13] = t2; q[14] = t2_o;
+                q[15] = dcc; q[16] = d10; q[17] = d10; q[18] = d11;
+#pragma unroll
+                for (int l = 0; l < 3; ++l)                       // x_r' as the CHAIN wavefront stores it (x(3) NOT re-wrapped)
+                    q[19 + l] = pose_sh[l] + (sol.Kr[l][0] * sol.nu[0] + sol.Kr[l][1] * sol.nu[1]);
+                q[22] = xn; q[23] = xn_o;
+                SmallSolve so2;
+                solve_small(q, dl.z0, dl.z1, dl.R00, dl.R01, dl.R10, dl.R11, so2);
+                const double n0 = so2.nu[0], n1 = so2.nu[1];
+                const double pc = (n0 * so2.Phi[0] + n1 * so2.Phi[2]) * n0 + (n0 * so2.Phi[1] + n1 * so2.Phi[3]) * n1;     // :69
+                const double d = dl.z2 - st.s[k];
+                const double sc = d * (1.0 / dl.s_cost) * d;                                                            // :71
+                const double like = (dl.w_pos != 0.0) ? (dl.w_pos * pc + sc) : sc;                                      // :74-75
+                if (like <= dl.s_thresh) { ll = like; ix = k; }                                                         // :78
+            }
+            // workgroup arg-min: butterflies, the four column wavefronts' winners through LDS (the helper wavefronts have left:
+            // a barrier counts live wavefronts only), one entry per workgroup for the next launch's reduce_partials_wave
+            wave_argmin(ll, ix);
+            if ((tid & 63) == 0) { na_ll[tid >> 6] = ll; na_ix[tid >> 6] = ix == INT64_MAX ? -1 : (int)ix; }
+            __syncthreads();
+            if (tid < 64) {
+                ll = tid < kGatherCols / 64 ? na_ll[tid] : INFINITY;
+                ix = (tid < kGatherCols / 64 && na_ix[tid] >= 0) ? (int64_t)na_ix[tid] : INT64_MAX;
+                if (ix == INT64_MAX) ll = INFINITY;
+                wave_argmin(ll, ix);
+                if (tid == 0) store_partial(dl.parts_out + blockIdx.x, ll, ix == INT64_MAX ? -1 : (int)ix, dl.seq_out);
+            }
         }
     }
 #ifdef EKF_GATHER_STAMPS
@@ -1182,21 +1352,6 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
 // ---------------------------------------------------------------------------------------------------
 // association (Correspondence.m:49-87): one thread per landmark, block arg-min, then a one-block finish
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool assoc_better(double la, int64_t ia, double lb, int64_t ib) {
-    // strict '<' on the likelihood, first (lowest) index wins ties (Correspondence.m:81)
-    return la < lb || (la == lb && ia < ib);
-}
-
-// arg-min over a wavefront under assoc_better's order (a total order: every lane ends with the same winner)
-__device__ __forceinline__ void wave_argmin(double &ll, int64_t &ix) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ol = __shfl_xor(ll, off);
-        const int64_t oi = __shfl_xor((long long)ix, off);
-        if (assoc_better(ol, oi, ll, ix)) { ll = ol; ix = oi; }
-    }
-}
-
 template <typename TS>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
@@ -1275,15 +1430,7 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
     if (host_partials) {
         // The HOST takes the arg-min over the workgroups' winners: ONE 16-byte store per workgroup into mapped host memory, payload
         // and sequence number together -- no ticket, no fence, no second reduction on the device.
-        if (tid == 0) {
-            typedef int part_v4 __attribute__((ext_vector_type(4)));
-            part_v4 v;
-            const long long lb = __double_as_longlong(ll);
-            v.x = (int)(lb & 0xffffffffll); v.y = (int)(lb >> 32);
-            v.z = ix == INT64_MAX ? -1 : (int)ix;
-            v.w = (int)((uint32_t)seq + assoc_part_mix((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z));
-            *reinterpret_cast<part_v4 *>(host_partials + blockIdx.x) = v;
-        }
+        if (tid == 0) store_partial(host_partials + blockIdx.x, ll, ix == INT64_MAX ? -1 : (int)ix, seq);
         return;
     }
     if (gridDim.x > 1) {
@@ -1532,7 +1679,7 @@ int gather_fuse_max_rows() { return kFuseMaxRows; }
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int, hipStream_t s) {
     // MFMA panel product at large landmark counts (EKF_PREDICT_MFMA=0/1 forces the VALU / MFMA kernel)
-    static const int force = [] { const char *v = getenv("EKF_PREDICT_MFMA"); return v ? atoi(v) : -1; }();
+    static const int force = ekf_tune_int("EKF_PREDICT_MFMA", -1);
     const bool mfma = force >= 0 ? force != 0 : a.n_mm >= 2048;
     if (mfma) {
         const int64_t nslices = (a.n_mm + 15) / 16;
@@ -1546,12 +1693,14 @@ hipError_t launch_predict(const DevState &st, const PredictArgs &a, int, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s) {
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dlp) {
     const int64_t n_mm = 2 * a.N;
     const int64_t grid = cdiv(n_mm > 0 ? n_mm : 1, kBlock);
+    DevLoopArgs dl = {};
+    if (dlp) dl = *dlp;
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_append<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a),
-        hipLaunchKernelGGL(k_append<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a));
+        hipLaunchKernelGGL(k_append<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl),
+        hipLaunchKernelGGL(k_append<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl));
     return hipGetLastError();
 }
 
@@ -1563,7 +1712,7 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
     pv.recv = nullptr; pv.slab = 0; pv.offset = 0; pv.Ij = 0; pv.patched = 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
-#define EKF_G(TS_, PRED_, FUSE_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_, FUSE_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
+#define EKF_G(TS_, PRED_, FUSE_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_, FUSE_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa, NoDevLoop{})
     if (fuse_downdate) {
         if (a.n_mm > kFuseMaxRows || grid != 1) return hipErrorInvalidValue;
         if (storage == 0) { if (fused_predict) EKF_G(double, true, true); else EKF_G(double, false, true); }
@@ -1572,6 +1721,23 @@ hipError_t launch_gather(const DevState &st, const CorrectArgs &a, const Predict
         if (storage == 0) { if (fused_predict) EKF_G(double, true, false); else EKF_G(double, false, false); }
         else              { if (fused_predict) EKF_G(float, true, false); else EKF_G(float, false, false); }
     }
+#undef EKF_G
+    return hipGetLastError();
+}
+
+int64_t gather_workgroups(const DevState &st, int64_t n_mm) { return cdiv(ekf_tiles_for(n_mm, st.tm.T) * st.tm.T, kGatherCols); }
+
+hipError_t launch_gather_devloop(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const DevLoopArgs &dl,
+                                 int storage, hipStream_t s) {
+    if (!dl.parts_in || !dl.rec || dl.nblk_in < 1 || a.n_mm < 2) return hipErrorInvalidValue;
+    const int64_t grid = gather_workgroups(st, a.n_mm);
+    PanelView pv;
+    pv.recv = nullptr; pv.slab = 0; pv.offset = 0; pv.Ij = 0; pv.patched = 0;
+    PredictArgs pa = {};
+    if (fused_predict) pa = *fused_predict;
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, false, PRED_, false, true>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa, dl)
+    if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
+    else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
 #undef EKF_G
     return hipGetLastError();
 }
@@ -1619,86 +1785,11 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
     pv.recv = recv; pv.slab = rank_stride; pv.offset = offset; pv.Ij = a.j >> st.tm.shift; pv.patched = patched ? 1 : 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
-#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa)
+#define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa, NoDevLoop{})
     if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
     else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }
 #undef EKF_G
     return hipGetLastError();
-}
-
-// Batched flush with the G operands staged through LDS (f64 tiles, T = 128, 32-row slabs) -- the production flush.
-// In k_downdate_w every wavefront re-loads its G values pair by pair with vector loads and waits for each of them
-// (L2 latency under full HBM load, 4x redundant across the workgroup's wavefronts).  Here the workgroup copies the
-// G slice of kChunk pairs (kChunk x 128 columns x 16 B) into LDS with one burst of coalesced loads, and the
-// per-pair loop then carries only LDS reads and the scalar K loads -- no vector-memory wait inside it.
-// Measured at 10k landmarks, 32 pairs: 0.77 ms vs 0.91 ms (profiles/round1_tuning.md, sweep 5).
-template <int kChunk>
-__global__ __launch_bounds__(kBlock) void k_flush_lds(const double *__restrict__ tiles, double *__restrict__ dst,
-                                                      const int2 *__restrict__ work, int64_t nwork,
-                                                      const double *__restrict__ Kp, const double *__restrict__ Gp,
-                                                      int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
-    constexpr int T = 128, kSlab = 32, kRowsPerWave = 8, kSlabsPerTile = 4;
-    __shared__ double2 Gs[kChunk][T];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t nitems = 8 * nwork * kSlabsPerTile;                 // 8 per-XCD streams (see k_downdate_w)
-    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t vi = tm.reverse ? nwork * kSlabsPerTile - 1 - (it >> 3) : (it >> 3);
-        const int64_t w = vi / kSlabsPerTile;
-        const int slab = (int)(vi - w * kSlabsPerTile);
-        const int2 ij = work[(it & 7) * nwork + w];
-        if (ij.x < 0) continue;                                       // padding of a shorter stream (uniform per workgroup)
-        const int row0 = slab * kSlab + wave * kRowsPerWave;
-        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)row0 * T + 2 * lane;
-        const double *__restrict__ tp = tiles + toff;
-        double *__restrict__ td = dst + toff;
-        double2 v[kRowsPerWave];
-#pragma unroll
-        for (int p = 0; p < kRowsPerWave; ++p) {
-            // the tile stream is touched once per launch: nontemporal, so that it does not evict the pending K/G vectors
-            // (the operands every workgroup re-reads) from L2 -- 0.80 -> 0.72 ms at 32 pairs (tuning log, sweep 9)
-            v[p].x = __builtin_nontemporal_load(tp + (int64_t)p * T);
-            v[p].y = __builtin_nontemporal_load(tp + (int64_t)p * T + 1);
-        }
-        const int64_t gcol0 = (int64_t)ij.y * T;
-        const int64_t krow = (int64_t)ij.x * T + row0;                // wave-uniform
-        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
-            const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
-            __syncthreads();                                          // everyone is done with the previous chunk
-            {
-                constexpr int kPer = kChunk * T / kBlock;             // G values each thread stages per chunk
-                double2 tmp[kPer];
-#pragma unroll
-                for (int q = 0; q < kPer; ++q) {                      // all loads in flight before the first LDS write
-                    const int e = tid + q * kBlock, col = e & (T - 1);
-                    const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;  // clamp: always a valid pair, written only if in range
-                    tmp[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
-                }
-#pragma unroll
-                for (int q = 0; q < kPer; ++q) {
-                    const int e = tid + q * kBlock, i = e >> 7, col = e & (T - 1);
-                    if (i < cn) Gs[i][col] = tmp[q];
-                }
-            }
-            __syncthreads();
-            for (int i = 0; i < cn; ++i) {
-                const double2 *__restrict__ k2 = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride) + krow;
-                const double2 ga = Gs[i][2 * lane], gb = Gs[i][2 * lane + 1];
-#pragma unroll
-                for (int p = 0; p < kRowsPerWave; ++p) {
-                    const double2 k = k2[p];                          // uniform address: scalar load
-                    v[p].x = rank2_apply(v[p].x, k, ga);
-                    v[p].y = rank2_apply(v[p].y, k, gb);
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < kRowsPerWave; ++p) {
-            __builtin_nontemporal_store(v[p].x, td + (int64_t)p * T);
-            __builtin_nontemporal_store(v[p].y, td + (int64_t)p * T + 1);
-        }
-    }
 }
 
 // Batched flush on the matrix cores (f64 tiles, T = 128) -- the production flush for two or more pending pairs.
@@ -1836,8 +1927,8 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                               int grid_cap, hipStream_t s, char *kname) {
     constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
     if constexpr (kHave) {
-        static const bool use_mfma = [] { const char *v = getenv("EKF_FLUSH_MFMA"); return !v || atoi(v) != 0; }();
-        static const int chunk_switch = [] { const char *v = getenv("EKF_FLUSH_MFMA_SWITCH"); return v ? atoi(v) : 26; }();
+        static const bool use_mfma = ekf_tune_int("EKF_FLUSH_MFMA", 1) != 0;
+        static const int chunk_switch = ekf_tune_int("EKF_FLUSH_MFMA_SWITCH", 26);
         // F32 tiles: also for a single pair -- the 64 x 128 work items stream the float tiles faster than the one-pair VALU kernel
         // (40 k landmarks: 4.4 ms vs 4.9 ms per pass); F64 tiles: the one-pair VALU kernel is the faster one (0.53 vs 0.56 ms)
         constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;
@@ -1862,20 +1953,9 @@ template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                      int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
-    static const bool use_xcd = [] { const char *v = getenv("EKF_FLUSH_XCD"); return !v || atoi(v) != 0; }();
+    static const bool use_xcd = ekf_tune_int("EKF_FLUSH_XCD", 1) != 0;
     if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)) return hipGetLastError();
     if constexpr (kLanes == 64 || kLanes == 32) {
-        static const bool use_lds = [] { const char *v = getenv("EKF_FLUSH_LDS"); return !v || atoi(v) != 0; }();
-        if constexpr (sizeof(TS) == 8 && T == 128 && kSlab == 32) {
-            if (npairs > 1 && use_xcd && use_lds && work_xcd && xcd_len > 0) {
-                int64_t grid = 8 * xcd_len * 4;
-                if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
-                hipLaunchKernelGGL((k_flush_lds<8>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)st.tiles, (double *)dstv,
-                                   work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
-                if (kname) snprintf(kname, 64, "k_flush_lds<8>");
-                return hipGetLastError();
-            }
-        }
         if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
             int64_t grid = 8 * xcd_len * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
@@ -1938,8 +2018,8 @@ static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *
 
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname) {
-    static const int slab1 = [] { const char *v = getenv("EKF_DOWNDATE_SLAB"); return v ? atoi(v) : 0; }();
-    static const int slabm = [] { const char *v = getenv("EKF_DOWNDATE_SLAB_BATCH"); return v ? atoi(v) : 0; }();
+    static const int slab1 = ekf_tune_int("EKF_DOWNDATE_SLAB", 0);
+    static const int slabm = ekf_tune_int("EKF_DOWNDATE_SLAB_BATCH", 0);
     const int slab = npairs > 1 ? slabm : slab1;
     return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname)
                         : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname);

@@ -25,7 +25,7 @@ def _colmajor(M):
 
 class Engine:
     def __init__(self, mode="known", capacity=1024, tile=0, storage="f64", device=0, rank=0, world=1, batch=1,
-                 async_flush=False, device_assoc=False, **overrides):
+                 async_flush=False, device_assoc=None, **overrides):
         self.lib = L.lib()
         cfg = L.EkfConfig()
         m = L.EKF_MODE_KNOWN if mode in ("known", "EKF_SLAM") else L.EKF_MODE_UC
@@ -35,7 +35,8 @@ class Engine:
         cfg.storage = L.EKF_STORE_F64 if storage == "f64" else L.EKF_STORE_F32
         cfg.device, cfg.rank, cfg.world, cfg.batch = int(device), int(rank), int(world), int(batch)
         cfg.async_flush = 1 if async_flush else 0
-        cfg.device_assoc = int(device_assoc)      # False / 0: host mirror, True / 1: device, waited for, 2: device, verified afterwards
+        if device_assoc is not None:              # None: the mode's default (uc: 3, the device-resident loop); include/ekfslam.h
+            cfg.device_assoc = int(device_assoc)  # 0: host mirror, 1: device, waited for, 2: device, verified before measure() returns
         for k, v in overrides.items():
             if k == "Rc":
                 cfg.Rc[0], cfg.Rc[1] = float(v[0]), float(v[1])

@@ -93,12 +93,20 @@ class _EkfBase:
         self._e.set_params(Rc=v)
 
     @property
-    def s_cost(self):
+    def s_cost(self):               # public assignable properties of the reference (EKF_SLAM.m:14-16)
         return self._e.cfg.s_cost
+
+    @s_cost.setter
+    def s_cost(self, v):
+        self._e.set_params(s_cost=v)
 
     @property
     def s_thresh(self):
         return self._e.cfg.s_thresh
+
+    @s_thresh.setter
+    def s_thresh(self, v):
+        self._e.set_params(s_thresh=v)
 
     # ---- methods ----
     def predict(self, u):
@@ -118,7 +126,11 @@ class _EkfBase:
     def append(self, u, R, landmarkPos, signature):
         self._e.append(u, R, landmarkPos, signature)
 
+    def _push_params(self):
+        pass
+
     def measure(self, laserData, u, landmark_list):
+        self._push_params()
         observed_LL = landmark_list.getLandmark(laserData, self.x)       # EKF_SLAM.m:102
         self.observed = observed_LL                                      # :103
         idx, loc = landmark_list.landmarkObj.table()
@@ -158,6 +170,15 @@ class EKF_SLAM_UC(_EkfBase):
     def __init__(self, capacity=_DEFAULT_CAPACITY, **engine_kw):
         super().__init__(capacity, **engine_kw)
         self.correspondence = Correspondence(.00000000001, 1000000000, 'EKF_SLAM_UC')
+
+    def _push_params(self):
+        """measure() associates with h.correspondence's cost / threshold (EKF_SLAM_UC.m:16,119): the property is public and
+        may be replaced or edited at any time, so its values go to the engine before every scan (as matlab/EKF_SLAM_UC.m's
+        pushParams does)."""
+        c = self.correspondence
+        cfg = self._e.cfg
+        if float(c.s_cost) != cfg.s_cost or float(c.s_thresh) != cfg.s_thresh:
+            self._e.set_params(s_cost=float(c.s_cost), s_thresh=float(c.s_thresh))
 
 
 class Correspondence:

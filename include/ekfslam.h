@@ -74,21 +74,37 @@ typedef struct ekf_config {
                                     batch = 1 that is the as-written update-step software-pipelined: the pass of step i
                                     beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
                                     async_flush = 0.  The second stream is confined to a CU mask that leaves 32 CUs
-                                    (EKF_ASYNC_RESERVE_CUS) to the corrections.  Pays when a batch's corrections take
+                                    to the corrections.  Pays when a batch's corrections take
                                     about as long as its pass; with batch = 1 it has measured slower than the in-place
                                     pass at every map size on one GPU (two stores defeat the cache). */
-    int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure, when w_pos == 0 (the reference's live likelihood is signature-only,
-                                    Correspondence.m:75, so the decision is a function of z(3) and s alone):
-                                    0 (default): the decision is taken from the host mirror of s -- no launch, no sync;
-                                    1: every observation runs the association kernel on the device (per-landmark phi_k,
-                                       Mahalanobis and signature cost, arg-min: Correspondence.m:49-87 as the reference
-                                       evaluates it) and the host WAITS for its decision;
-                                    2: the kernel runs for every observation all the same, but the host dispatches on its
-                                       mirror's decision without waiting and VERIFIES every device decision against it before
-                                       ekf_measure returns (EKF_ERR_STATE on a mismatch).
-                                    With w_pos != 0 the device decides (and is waited for) whatever this says;
-                                    ekf_associate() always runs on the device. */
-    int32_t reserved[5];
+    int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure (EKF_SLAM_UC.m:107-151), when w_pos == 0 (the reference's live likelihood is
+                                    signature-only, Correspondence.m:75, so WHETHER a row appends or corrects is a function of z(3) and
+                                    s alone and the host's mirror of s can predict it):
+                                    3 (default of EKF_MODE_UC): the device-resident loop.  Every observation's association runs on
+                                       the device (per-landmark phi_k, Mahalanobis and signature cost, thresholded arg-min:
+                                       Correspondence.m:49-87 as the reference evaluates it) and its decision is CONSUMED on the
+                                       device: the correction's gather kernel takes its landmark from the association's winners, and
+                                       evaluates the next observation's association in its own epilogue (one launch per
+                                       observation); an append checks that nothing passed the threshold.  The host queues all m rows
+                                       without a single wait -- which branch it queues is its mirror's prediction -- and the decisions
+                                       the device took come back as records that are checked against the prediction later: the
+                                       next ekf_measure checks what has landed, every call that synchronises or reads or loads state
+                                       (ekf_sync, ekf_get_*, ekf_set_*, ...) checks the rest first and returns EKF_ERR_STATE on a
+                                       mismatch (it cannot happen unless s was changed behind the library's back).  Unsharded
+                                       handles; a sharded handle decides as 0.
+                                    0: the decision is taken from the host mirror of s -- no association launch at all;
+                                    1: the association kernel runs for every observation and the host WAITS for its decision;
+                                    2: the kernel runs for every observation, the host dispatches on its mirror's decision (passed
+                                       to the gather kernel as an argument) and VERIFIES every device decision before ekf_measure
+                                       returns (EKF_ERR_STATE on a mismatch).
+                                    With w_pos != 0 the branch cannot be predicted: the device decides and is waited for (as 1)
+                                    whatever this says; ekf_associate() always runs on the device and waits. */
+    int32_t pass_direction;      /* the pass over P: 0 (default) = every other pass walks its work list backwards when the shard's
+                                    tile store exceeds the 256 MiB Infinity Cache (what one pass wrote last the next reads first,
+                                    on-die), forwards otherwise; 1 = always forwards; 2 = always alternate.  Same bits. */
+    int32_t force_sharded;       /* 1: run the sharded code path (row-panel extraction, exchange, sharded gather) although
+                                    world == 1 -- how that path is exercised and timed on a single GPU */
+    int32_t reserved[3];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: interleaved A/B of one EKF_* environment knob on the one-pair pass (scripts/time_flush.py).
+# The knobs exist only in the tuning build: make -C ekf_slam_amd/csrc tuning (libekfslam_tuning.so, -DEKF_TUNING).
 # Usage: scripts/ab_env.sh <tag> <VAR> "<values>" "<landmark list>" [batch]
 set -e -o pipefail
 TAG=$1; VAR=$2; VALS=$3; LMS=${4:-10000}; B=${5:-1}
@@ -10,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for round in 1 2 3; do
   for L in $LMS; do
     for V in $VALS; do
-      env $VAR=$V timeout -k 10 120 python3 $REPO/scripts/time_flush.py --landmarks $L --batch $B --batches $([ $B = 1 ] && echo 256 || echo 12) --label "$VAR=$V" 2>/dev/null | grep '^{' >> $OUT/ab.jsonl
+      env EKF_LIB_PATH=$REPO/ekf_slam_amd/libekfslam_tuning.so $VAR=$V timeout -k 10 120 python3 $REPO/scripts/time_flush.py --landmarks $L --batch $B --batches $([ $B = 1 ] && echo 256 || echo 12) --label "$VAR=$V" 2>/dev/null | grep '^{' >> $OUT/ab.jsonl
     done
   done
 done

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: A/B of the alternating pass direction (EKF_PASS_ALTERNATE=0/1), interleaved rounds, several map sizes.
+# GPU box: A/B of the alternating pass direction (cfg.pass_direction = 1 / 2), interleaved rounds, several map sizes.
 # Usage: scripts/ab_pass_direction.sh <tag>
 set -e -o pipefail
 TAG=${1:-alt}
@@ -11,7 +11,7 @@ for round in 1 2 3; do
   for L in 10000 7000 5000 3536; do
     for B in 1 32; do
       for ALT in 0 1; do
-        EKF_PASS_ALTERNATE=$ALT timeout -k 10 120 python3 $REPO/scripts/time_flush.py --landmarks $L --batch $B --batches $([ $B = 1 ] && echo 256 || echo 12) --label "alt=$ALT" 2>/dev/null | grep '^{' >> $OUT/ab.jsonl
+        timeout -k 10 120 python3 $REPO/scripts/time_flush.py --landmarks $L --batch $B --batches $([ $B = 1 ] && echo 256 || echo 12) --pass-direction $((ALT + 1)) --label "alt=$ALT" 2>/dev/null | grep '^{' >> $OUT/ab.jsonl
       done
     done
   done

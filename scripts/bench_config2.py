@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--host-decision", action="store_true",
                     help="cfg.device_assoc = 0: take the association decision from the host mirror of s (legitimate: the reference's "
                          "live likelihood is signature-only, Correspondence.m:75); default here is the device kernels per observation")
+    ap.add_argument("--waited", action="store_true",
+                    help="cfg.device_assoc = 1: k_associate per observation, the host waits for every decision (round 2's primary mode); "
+                         "default here is cfg.device_assoc = 3, the device-resident loop")
     ap.add_argument("--verified", action="store_true",
                     help="cfg.device_assoc = 2: k_associate runs for every observation, the host dispatches on its mirror's decision "
                          "without waiting and verifies every device decision before measure() returns")
@@ -41,7 +44,7 @@ def main():
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     N = args.landmarks
     _, run = make_run(N, 20260102, 2 + args.steps, policy="nearest", m=args.m)
-    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, device_assoc=(0 if args.host_decision else 2 if args.verified else 1))
+    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, device_assoc=(0 if args.host_decision else 2 if args.verified else 1 if args.waited else 3))
     lm = Landmark('SYNTHETIC')
     t0 = time.perf_counter()
     for u, scan in run[:2]:                      # warm-up sweep: appends every landmark
@@ -88,7 +91,8 @@ def main():
                                   "iteration = predict + measure() over the %d nearest landmarks" % (N, args.m),
                       "deferred_batch": args.batch, "tile": args.tile, "warmup_sweep_s": t_sweep,
                       "device_association": ("host mirror" if args.host_decision else "device, verified after dispatch" if args.verified
-                                             else "device, waited for"),
+                                             else "device, waited for" if args.waited else
+                                             "device-resident loop: decision produced and consumed on the device, no host wait"),
                       "associate": assoc, "gather_avg_us": (ms_ga / n_ga * 1e3) if n_ga else None,
                       "state_finite": bool(np.isfinite(x_end).all())}}
     if args.check:

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--storage", default="f64")
     ap.add_argument("--label", default="")
     ap.add_argument("--async-flush", action="store_true")
+    ap.add_argument("--pass-direction", type=int, default=0, help="cfg.pass_direction: 0 auto, 1 forwards, 2 alternate")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP events around the kernels: the throughput column is then undisturbed")
     a = ap.parse_args()
     import bench
@@ -33,7 +34,7 @@ def main():
     w, x, s, d, U = bench.make_state(N, 20260104)
     nsteps = a.batch * a.batches
     steps = bench.make_steps(w, N, a.batch * 2 + nsteps, [.01, 5.0])
-    e = Engine(capacity=N, tile=a.tile, batch=a.batch, storage=a.storage, async_flush=a.async_flush)
+    e = Engine(capacity=N, tile=a.tile, batch=a.batch, storage=a.storage, async_flush=a.async_flush, pass_direction=a.pass_direction)
     e.load_lowrank_state(x, s, d, U)
     warm, timed = e.marshal_steps(steps[:a.batch * 2]), e.marshal_steps(steps[a.batch * 2:])
     for i in range(warm["m"]):

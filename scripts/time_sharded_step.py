@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the SHARDED form of the as-written update-step costs beyond its pass over P, measured on ONE GPU: the handle is forced
-onto the sharded code path (EKF_FORCE_SHARDED=1: k_rowpanel -> all-gather -> k_gather<sharded> -> downdate) with a 1-rank RCCL
+onto the sharded code path (cfg.force_sharded = 1: k_rowpanel -> all-gather -> k_gather<sharded> -> downdate) with a 1-rank RCCL
 communicator (the all-gather is then a device copy by RCCL's kernel: its launch and kernel cost are in, its xGMI hops are
 not), and timed beside the unsharded handle on the same steps.  Run under `rocprofv3 --kernel-trace --stats` for the
 per-kernel split.
@@ -38,8 +38,7 @@ def main():
     if a.async_flush:
         legs += [("unsharded_async", "0", True), ("sharded_1rank_rccl_async", "1", True)]
     for name, forced, asy in legs:
-        os.environ["EKF_FORCE_SHARDED"] = forced
-        e = Engine(capacity=N, batch=a.batch, async_flush=asy)
+        e = Engine(capacity=N, batch=a.batch, async_flush=asy, force_sharded=int(forced))
         if forced == "1":
             raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
             assert L.lib().ekf_comm_unique_id(raw) == 0

@@ -37,7 +37,8 @@ if len(sys.argv) > 2:
     plan = eval(sys.argv[2])
 for tile, batch, slabs in plan:
     for slab in slabs:
-        env = dict(os.environ, EKF_DOWNDATE_SLAB_BATCH=str(slab), EKF_DOWNDATE_SLAB=str(slab))
+        env = dict(os.environ, EKF_LIB_PATH=os.path.join(ROOT, 'ekf_slam_amd', 'libekfslam_tuning.so'),  # -DEKF_TUNING build: make -C ekf_slam_amd/csrc tuning
+                   EKF_DOWNDATE_SLAB_BATCH=str(slab), EKF_DOWNDATE_SLAB=str(slab))
         out = subprocess.run([sys.executable, "-c", CHILD, str(N), str(tile), str(batch)], env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else out.stderr[-400:]
         print("tile %3d batch %3d slab %3d : %s" % (tile, batch, slab, line), flush=True)

@@ -1,17 +1,18 @@
 """GPU: BASELINE.json configs[1] at its stated size -- 1 000 landmarks, unknown correspondence (EKF_SLAM_UC.m +
 Correspondence.m), F64, one GPU -- against the structured oracle on the same inputs (seed 20260102,
 a warm-up sweep appends all 1 000 landmarks through measure(), then SLAM iterations of 1 predict + measure() over the 8
-nearest landmarks).  Run twice: with the association decided per observation by the device kernels (k_associate: per-landmark
-phi_k, Mahalanobis and signature cost, arg-min -- what the reference evaluates, Correspondence.m:49-87) and with the
-host-mirror shortcut that is legitimate because the reference's live likelihood is signature-only (Correspondence.m:75); both
-must give the same state bit for bit -- and so must the third mode (cfg.device_assoc = 2), in which the kernel runs for every
-observation but the host dispatches on its mirror's decision and verifies the device's afterwards."""
+nearest landmarks, 200 of them as SURVEY.md 8d states).  Run in all four association modes (include/ekfslam.h, cfg.device_assoc):
+the DEFAULT device-resident loop (3: the association's decision is produced and consumed on the device -- k_associate for the
+first row of a scan, the epilogue of the previous row's gather kernel for the others -- no host wait anywhere), the waited
+device association (1), the host-mirror shortcut (0: legitimate because the reference's live likelihood is signature-only,
+Correspondence.m:75) and the verified-after-dispatch mode (2).  All four must give the same state bit for bit, and the oracle's
+to 1e-6."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 REL = 1e-6
-N, M, ITERS = 1000, 8, 40
+N, M, ITERS = 1000, 8, 200
 
 
 def rel_err(a, b):
@@ -24,8 +25,10 @@ def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     from oracle.ekf_structured import StructuredEKF
     _, run = make_run(N, 20260102, 2 + ITERS, policy="nearest", m=M)
-    gpus = {"device": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=True), "host": EKF_SLAM_UC(capacity=N, batch=8),
+    gpus = {"device": EKF_SLAM_UC(capacity=N, batch=8),                       # the default: device-resident loop
+            "waited": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=1), "host": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=0),
             "verified": EKF_SLAM_UC(capacity=N, batch=8, device_assoc=2)}     # device kernels in the stream, checked after dispatch
+    assert gpus["device"]._e.cfg.device_assoc == 3
     lms = {k: Landmark('SYNTHETIC') for k in gpus}
     ref, lr = StructuredEKF(N, "uc"), SyntheticLandmark()
     for t, (u, scan) in enumerate(run):
@@ -40,7 +43,7 @@ def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
     ex, eP = rel_err(xd, ref.x), rel_err(Pd, ref.P)
     print("1k UC: %d iterations x %d observations, rel err x %.2e P %.2e" % (ITERS, M, ex, eP))
     assert ex < REL and eP < REL
-    for k in ("host", "verified"):
+    for k in ("waited", "host", "verified"):
         np.testing.assert_array_equal(gpus[k].x, xd)
         np.testing.assert_array_equal(gpus[k].P, Pd)
     np.testing.assert_array_equal(gpus["device"].s, ref.s)

@@ -208,65 +208,53 @@ def test_mfma_flush_equals_immediate_bitwise(batch):
     np.testing.assert_array_equal(dfr.digest(), imm.digest())      # fixed reduction order: equal states, equal digests
 
 
-_FLUSH_CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, sys.argv[1])
-from ekf_slam_amd import Engine
-storage, tile, batch, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-N = 300
-rng = np.random.default_rng(71)
-n = 3 + 2 * N
-x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N)])
-U = rng.normal(0, 0.05, size=(n, 6))
-P = np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T
-e = Engine(capacity=N, tile=tile, storage=storage, batch=batch)
-e.set_state(x, P, np.arange(1, N + 1.0))
-for step in range(2 * batch + 3):
-    e.predict([0.1, 2.0])
-    z = [rng.uniform(1, 30), rng.uniform(1, 359)]
-    e.correct(z, np.diag([z[0] * .01, z[1] * 5.0]), int(rng.integers(0, N)))
-np.save(out, e.get_P())
-"""
+def _flush_run(storage, tile, batch, **cfg):
+    """2*batch + 3 corrections on a 300-landmark map; returns P (the final get_P flushes the partial batch)."""
+    from ekf_slam_amd import Engine
+    N = 300
+    rng = np.random.default_rng(71)
+    n = 3 + 2 * N
+    x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N)])
+    U = rng.normal(0, 0.05, size=(n, 6))
+    P = np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T
+    e = Engine(capacity=N, tile=tile, storage=storage, batch=batch, **cfg)
+    e.set_state(x, P, np.arange(1, N + 1.0))
+    for step in range(2 * batch + 3):
+        e.predict([0.1, 2.0])
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        e.correct(z, np.diag([z[0] * .01, z[1] * 5.0]), int(rng.integers(0, N)))
+    name = e.downdate_kernel_name()[0]
+    Pout = e.get_P()
+    e.close()
+    return Pout, name
 
 
-@pytest.mark.parametrize("storage,tile,batch", [("f32", 256, 5), ("f32", 256, 12), ("f32", 256, 33), ("f64", 128, 33)])
-def test_mfma_flush_equals_valu_flush_bitwise(tmp_path, storage, tile, batch):
-    """The matrix-core flush against the VALU flush it replaces (EKF_FLUSH_MFMA=0, read once per process -> child processes).
-    With F32 tiles a deferred run is not bit-equal to an immediate one (the tiles are rounded to float once per flush, not
-    once per correction), so this is the bitwise check for the F32 instance: same f64 FMA chain, same single rounding."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("1", "0"):
-        out = str(tmp_path / ("P_%s.npy" % flag))
-        env = dict(os.environ, EKF_FLUSH_MFMA=flag)
-        r = subprocess.run([sys.executable, "-c", _FLUSH_CHILD, root, storage, str(tile), str(batch), out], env=env,
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(out))
-    assert np.isfinite(outs[0]).all()
-    assert outs[0].tobytes() == outs[1].tobytes()
+@pytest.mark.parametrize("storage,tile,valu_tile,batch", [("f32", 256, 128, 5), ("f32", 256, 128, 12), ("f32", 256, 128, 33),
+                                                          ("f64", 128, 64, 33), ("f64", 128, 64, 7)])
+def test_mfma_flush_equals_valu_flush_bitwise(storage, tile, valu_tile, batch):
+    """The matrix-core flush (f64 tiles T = 128, f32 tiles T = 256) against the VALU flush k_downdate_w with several pairs, which
+    the same engine runs at the next smaller tile edge -- the tile edge changes the kernel, not the arithmetic (per element: the
+    pending pairs in slot order, two FMAs each; one rounding to float per flush with F32 tiles).  With F32 tiles a deferred run is
+    not bit-equal to an immediate one (rounded once per flush, not once per correction), so this is the bitwise check of the
+    F32 instance."""
+    P_mfma, k_mfma = _flush_run(storage, tile, batch)
+    P_valu, k_valu = _flush_run(storage, valu_tile, batch)
+    assert k_mfma.startswith("k_flush_mfma") and k_valu.startswith("k_downdate_w"), (k_mfma, k_valu)
+    assert np.isfinite(P_mfma).all()
+    assert P_mfma.tobytes() == P_valu.tobytes()
 
 
 @pytest.mark.parametrize("storage,tile,batch", [("f64", 16, 1), ("f64", 128, 1), ("f64", 128, 6), ("f32", 256, 3), ("f64", 64, 4)])
-def test_pass_direction_does_not_change_a_bit(tmp_path, storage, tile, batch):
+def test_pass_direction_does_not_change_a_bit(storage, tile, batch):
     """Above 256 MiB of tiles every other pass over P walks its work list backwards (the Infinity Cache then serves what the
     previous pass wrote last).  Every element is updated independently, so the order must not matter: forced on
-    for a small map (EKF_PASS_ALTERNATE=1, read once per process -> child processes), every pass kernel -- generic, one-pair
-    streaming, VALU and MFMA flushes -- against always-forwards, bit for bit.  (At full size the 10 k-landmark tests run with
-    the alternation on by itself.)"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag in ("1", "0"):
-        out = str(tmp_path / ("P_%s.npy" % flag))
-        env = dict(os.environ, EKF_PASS_ALTERNATE=flag)
-        r = subprocess.run([sys.executable, "-c", _FLUSH_CHILD, root, storage, str(tile), str(batch), out], env=env,
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(out))
-    assert np.isfinite(outs[0]).all()
-    assert outs[0].tobytes() == outs[1].tobytes()
+    for a small map (cfg.pass_direction = 2), every pass kernel -- generic, one-pair streaming, VALU and MFMA flushes -- against
+    always-forwards (cfg.pass_direction = 1), bit for bit.  (At full size the 10 k-landmark tests run with the alternation on by
+    itself.)"""
+    P_alt, _ = _flush_run(storage, tile, batch, pass_direction=2)
+    P_fwd, _ = _flush_run(storage, tile, batch, pass_direction=1)
+    assert np.isfinite(P_alt).all()
+    assert P_alt.tobytes() == P_fwd.tobytes()
 
 
 def test_marshalled_steps_equal_plain_calls():

@@ -154,7 +154,6 @@ _CHILD = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np
-os.environ["EKF_FORCE_SHARDED"] = "1"
 import ctypes
 from ekf_slam_amd import Engine, _lib as L
 rng = np.random.default_rng(31)
@@ -163,8 +162,7 @@ x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, 2 * N)])
 U = rng.normal(0, 0.05, (n, 6)); P = np.diag(rng.uniform(0.01, 0.1, n)) + U @ U.T
 s = np.arange(1, N + 1.0)
 mode = sys.argv[1]
-e = Engine(capacity=N, tile=32, batch=4)
-os.environ["EKF_FORCE_SHARDED"] = "0"
+e = Engine(capacity=N, tile=32, batch=4, force_sharded=1)     # the sharded code path with one rank (cfg.force_sharded)
 ref = Engine(capacity=N, tile=32, batch=4)
 e.set_state(x, P, s); ref.set_state(x, P, s)
 if mode == "rccl":
@@ -204,10 +202,7 @@ if mode == "rccl":
     obs = np.array([[5.0, 40.0, 1.0], [6.0, 50.0, 2.0], [7.0, 60.0, 3.0], [8.0, 70.0, N + 1.0]])
     idx = np.arange(1, N + 2, dtype=np.float64); loc = rng.uniform(-20, 20, (N + 1, 2))
     e2 = Engine(capacity=N + 2, tile=32, batch=4); r2 = Engine(capacity=N + 2, tile=32, batch=4)
-    # e2 was created with EKF_FORCE_SHARDED=0 in the environment -> make a sharded twin explicitly
-    os.environ["EKF_FORCE_SHARDED"] = "1"
-    e3 = Engine(capacity=N + 2, tile=32, batch=4)
-    os.environ["EKF_FORCE_SHARDED"] = "0"
+    e3 = Engine(capacity=N + 2, tile=32, batch=4, force_sharded=1)
     raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
     assert L.lib().ekf_comm_unique_id(raw) == 0
     e3.comm_init(raw.raw)
@@ -220,9 +215,7 @@ if mode == "rccl":
     np.testing.assert_array_equal(e3.get_P(), r2.get_P())
     # unknown correspondence with the position cost in the likelihood, whole scan through ekf_measure on the sharded handle:
     # every row's association exchanges its candidates (ekf_associate_begin -> ncclAllGather -> finish inside the library)
-    os.environ["EKF_FORCE_SHARDED"] = "1"
-    e4 = Engine(mode="uc", capacity=N + 2, tile=32, batch=4)
-    os.environ["EKF_FORCE_SHARDED"] = "0"
+    e4 = Engine(mode="uc", capacity=N + 2, tile=32, batch=4, force_sharded=1)
     r4 = Engine(mode="uc", capacity=N + 2, tile=32, batch=4)
     raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
     assert L.lib().ekf_comm_unique_id(raw) == 0
