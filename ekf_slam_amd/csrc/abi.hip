@@ -700,13 +700,15 @@ int32_t collect_decision(ekf_handle *h, AssocHostPartial *set, int32_t nblk, int
 // exchange == false: the decision of this launch is final (unsharded, or sharded with the signature-only likelihood, which every
 // shard evaluates identically from replicated data); exchange == true (sharded): this shard nominates among the landmarks whose
 // diagonal block it holds and leaves its candidate -- and, want_costs, their position costs -- in the send area
+// fold_predict (device-resident measure loop): a recorded predict(u) is carried out BY the association launch (it is k_predict and
+// k_associate in one), so the scan's first row costs no k_predict launch and its correction folds nothing
 int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocHostPartial *host_set_dev, int32_t seq,
-                     bool exchange = false, bool want_costs = false) {
+                     bool exchange = false, bool want_costs = false, bool fold_predict = false) {
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
     REQUIRE(h, exchange || h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
             "associate: with w_pos != 0 a sharded handle needs the candidates of the other shards (ekf_comm_init, or "
             "ekf_associate_begin / your all-gather / ekf_associate_finish)");
-    {
+    if (!fold_predict) {
         const int32_t rcp = materialize_predict(h);
         if (rcp) return rcp;
     }
@@ -719,7 +721,8 @@ int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocH
     TimedLaunch tl(h, EKF_KERNEL_ASSOCIATE);
     HIPCHK(h, launch_associate(h->st, a, exchange ? (want_costs ? h->send + 4 : nullptr) : h->d_pos_cost, h->d_sig_cost,
                                h->d_partial, h->d_ticket, h->d_decision, exchange ? nullptr : host_set_dev, seq,
-                               exchange ? h->send : nullptr, h->storage, h->stream));
+                               exchange ? h->send : nullptr, h->storage, h->stream, (fold_predict && h->have_pp) ? &h->pp : nullptr));
+    if (fold_predict && h->have_pp) { h->have_pp = false; h->cur ^= 1; }       // the launch wrote the predicted state to the other buffer
     return EKF_OK;
 }
 
@@ -1217,7 +1220,8 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
             DevLoopArgs dl = {};
             if (!nxt.have) {                                               // EKF_SLAM_UC.m:119, as a launch of its own
                 nxt.set = h->loop_set ^ 1; nxt.seq = next_assoc_seq(h); nxt.nblk = assoc_blocks(h->N);
-                rc = launch_assoc(h, z, R, h->d_lparts + (int64_t)nxt.set * h->lparts_stride, nxt.seq);
+                rc = launch_assoc(h, z, R, h->d_lparts + (int64_t)nxt.set * h->lparts_stride, nxt.seq, false, false,
+                                  /*fold_predict*/ !is_new);       // an append materialises the predict anyway
                 if (rc) return rc;
                 h->loop_set = nxt.set;
             }

@@ -161,9 +161,11 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 // finishing kernel); decision: device copy.  host_partials != nullptr (mapped host memory, one entry per workgroup): NO cross-workgroup
 // step on the device at all -- every workgroup stores its winner there and the HOST takes the arg-min over the ceil(N / kAssocBlock)
 // entries once each carries `seq` (the ticket + release / acquire hand-over it replaces was ~4 of the kernel's 9 us)
+// fused_predict != nullptr: the launch is ALSO k_predict -- the recorded predict(u) is applied to what the kernel reads and the
+// predicted pose / Prr / strip / Q are written to state buffer a.cur ^ 1 (the caller flips its buffer index afterwards)
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, int *ticket, AssocDecision *decision, AssocHostPartial *host_partials, int seq,
-                            double *cand, int storage, hipStream_t s);
+                            double *cand, int storage, hipStream_t s, const PredictArgs *fused_predict = nullptr);
 // cand (nullptr or 4 device doubles): this shard's candidate {likelihood, index or -1, 0, 0} for the all-gather of a sharded
 // association; launch_assoc_merge takes the arg-min over the `world` gathered contributions of `count` doubles each (candidate,
 // then -- want_costs -- N position costs) and writes the decision like launch_associate does

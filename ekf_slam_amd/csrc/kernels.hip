@@ -268,6 +268,24 @@ __device__ __forceinline__ void wave_argmin(double &ll, int64_t &ix) {
     }
 }
 
+// The same arg-min when few lanes hold a candidate at all (lanes without one carry ix == INT64_MAX).  With the reference's live
+// likelihood (signature cost only, Correspondence.m:75) at most the landmarks whose signature lies within the threshold of z(3)
+// are candidates -- normally ONE in the whole map -- so the butterfly (6 steps of four ds_bpermute each, ~900 clocks at the tail of
+// a latency chain) is replaced by a ballot and, for a single candidate, two v_readlane.  Same result in every case.
+__device__ __forceinline__ void wave_argmin_sparse(double &ll, int64_t &ix) {
+    const unsigned long long m = __ballot(ix != INT64_MAX);
+    if (m == 0ull) { ll = INFINITY; ix = INT64_MAX; return; }                      // (wave-uniform branches)
+    if ((m & (m - 1ull)) == 0ull) {
+        const int src = __ffsll((long long)m) - 1;
+        const int lo = __builtin_amdgcn_readlane(__double2loint(ll), src), hi = __builtin_amdgcn_readlane(__double2hiint(ll), src);
+        const int il = __builtin_amdgcn_readlane((int)(ix & 0xffffffffll), src), ih = __builtin_amdgcn_readlane((int)(ix >> 32), src);
+        ll = __hiloint2double(hi, lo);
+        ix = ((int64_t)ih << 32) | (int64_t)(uint32_t)il;
+        return;
+    }
+    wave_argmin(ll, ix);
+}
+
 // One self-validating 16-byte entry (kernels.h: AssocHostPartial): payload and launch number in ONE store instruction.
 __device__ __forceinline__ void store_partial(AssocHostPartial *dst, double ll, int index, int seq) {
     typedef int part_v4 __attribute__((ext_vector_type(4)));
@@ -295,7 +313,7 @@ __device__ __forceinline__ void reduce_partials_wave(const AssocHostPartial *__r
         if (got != seq) bad = 1;
         else if (v.z >= 0 && assoc_better(pl, (int64_t)v.z, bl, bi)) { bl = pl; bi = v.z; }
     }
-    wave_argmin(bl, bi);
+    wave_argmin_sparse(bl, bi);
     bad = __any(bad);
     ll = bl;
     ix = bad ? -2 : (bi == INT64_MAX ? -1 : (int)bi);
@@ -923,11 +941,16 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     //     the helper wavefronts -- the critical path -- spent waiting for them; behind it the column lanes have ~3 000 clocks of
     //     slack until the solve is published (scripts/probe_gather_phases.py).
     // 32 pairs: a 64-pair variant (344 VGPRs, one workgroup per CU) was slower under an asynchronous flush (tuning log, sweep 12)
-    constexpr int kPre = 32;
+    // (the device-loop instance splits the same registers: 16 pairs of this operand + 16 of the complementary one its epilogue needs)
+    constexpr int kPre = kDev ? 16 : 32;
     const int npre = do_patch ? (npend < kPre ? npend : kPre) : 0;
     const int64_t pad_cols = st.tm.padded(a.n_mm);
     const int64_t ps2 = st.pair_stride / 2;
     double2 pre[kPre];
+    double2 oth[kDev ? kPre : 1];                                 // kDev: the OTHER operand of the same pairs (K_i(c,:) left of j, G_i(:,c) right)
+    double dcc = 0.0, dlo = 0.0;                                  // kDev: base of the column's own diagonal entry (and, odd columns, the one left of it)
+    bool next_assoc = false;
+    if constexpr (kDev) next_assoc = dl.parts_out != nullptr;
     {
         // unconditional, clamped addresses (a predicated form lets the compiler sink the loads below the barrier, next to their
         // use); slots past npend repeat the last pending one (cache hits), c is clamped into the padded vector
@@ -938,6 +961,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         const uint32_t lane_off = cc + (rowpart ? 0u : krel);
         const char *__restrict__ ub = reinterpret_cast<const char *>(st.Gp);
         const uint32_t lane_bytes = lane_off * 16u;              // < 2^32: see below
+        const uint32_t oth_bytes = (cc + (rowpart ? krel : 0u)) * 16u;
         // slot offsets advance incrementally around the ring (scalar unit: one add, one wrap test per pair)
         // (32-bit: 2 * pcap * pair_stride / 2 <= 256 * 2 * capacity elements of 16 bytes stays far below 2^32)
         const uint32_t step = (uint32_t)ps2, wrap = (uint32_t)st.pcap * step;
@@ -953,12 +977,22 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     pre[g0 + t] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + lane_bytes);
+                    if constexpr (kDev) oth[g0 + t] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + oth_bytes);
                     if (g0 + t + 1 < npre) { off += step; if (off == wrap) off = 0; }
                 }
             }
         }
     }
 
+
+    if constexpr (kDev) {
+        // the epilogue's own diagonal entries, requested now (tile store: the one HBM-latency load of the epilogue); clamped,
+        // unconditional: canonical (2k,2k) on even columns, (2k+1,2k) and (2k+1,2k+1) -- one load -- on odd ones
+        const int64_t cl = live ? c : (c & 1);
+        if (c & 1) pmm_low_pair<TS>(tiles, st.tm, cl, cl - 1, dlo, dcc);
+        else dcc = pmm_low<TS>(tiles, st.tm, cl, cl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // (3) every lane applies the pending pairs to its own two row entries while the helper wavefronts run the solve
     if (live && do_patch) {
@@ -1030,6 +1064,45 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             }
         }
     }
+    if constexpr (kDev) {
+        // ... and, while the helper wavefronts still run the solve, the pending pairs on the epilogue's diagonal entries (dcc; odd
+        // columns also dlo, the one left of it), in slot order (pmm_live's chain, as k_associate runs it): everything of the next
+        // observation's association that does not depend on this correction.  The first kPre pairs' operands are in registers:
+        // `pre` holds G_i(:,c) left of j and K_i(c,:) right of it, `oth` the other one.
+        if (next_assoc) {
+            const int64_t cl = live ? c : (c & 1);                // clamped: unconditional loads, no shuffles under divergence
+#pragma unroll
+            for (int g0 = 0; g0 < kPre; g0 += 8)
+                if (g0 < npre) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const double2 kc = rowpart ? oth[g0 + t] : pre[g0 + t], gc = rowpart ? pre[g0 + t] : oth[g0 + t];
+                        const double2 gl = make_double2(__shfl_xor(gc.x, 1), __shfl_xor(gc.y, 1));   // the partner column's G_i
+                        const double v0 = rank2_apply(dcc, kc, gc), v1 = rank2_apply(dlo, kc, gl);      // dlo, odd lanes: K_i(2k+1,:) G_i(:,2k)
+                        dcc = g0 + t < npre ? v0 : dcc; dlo = g0 + t < npre ? v1 : dlo;
+                    }
+                }
+            // more than kPre pending pairs: 8 pairs' operands in flight together, applied in order
+            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + cl;
+            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + cl;
+            for (int i0 = npre; i0 < npend; i0 += 8) {
+                double2 kk[8], gg[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t so = (int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2;
+                    kk[q] = kp[so]; gg[q] = gp[so];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const double2 gl = make_double2(__shfl_xor(gg[q].x, 1), __shfl_xor(gg[q].y, 1));
+                    if (i0 + q < npend) {
+                        dcc = rank2_apply(dcc, kk[q], gg[q]);
+                        dlo = rank2_apply(dlo, kk[q], gl);
+                    }
+                }
+            }
+        }
+    }
     EKF_STAMP();                                                  // 2: patches done
     __syncthreads();                                              // barrier B: the helpers' results are in LDS
     EKF_STAMP();                                                  // 3: solve available
@@ -1098,7 +1171,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         }
     }
     if constexpr (kDev) {
-        if (dl.parts_out != nullptr) {                            // uniform
+        if (next_assoc) {                                         // uniform
             // ---- the NEXT observation's association (Correspondence.m:49-87) on the state this correction leaves.  Landmark
             //      k = c / 2 is scored by its even column lane; everything it needs is in this lane pair's registers (x', strip',
             //      this correction's K(c,:), G(:,c)) or in the workgroup's LDS (Prr before the correction, K_r, G_r, nu) -- except
@@ -1106,32 +1179,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             __shared__ double na_ll[kGatherCols / 64];
             __shared__ int na_ix[kGatherCols / 64];
             const bool odd = (c & 1) != 0;
-            const int64_t cl = live ? c : (c & 1);                // clamped: unconditional loads, no shuffles under divergence
-            // own diagonal entry and, on odd columns, the one left of it: canonical (2k,2k) | (2k+1,2k), (2k+1,2k+1) ...
-            double dcc = 0.0, dlo = 0.0;
-            if (odd) pmm_low_pair<TS>(tiles, st.tm, cl, cl - 1, dlo, dcc);
-            else dcc = pmm_low<TS>(tiles, st.tm, cl, cl);
-            // ... minus the pending pairs in slot order (pmm_live's chain, as k_associate runs it), 8 pairs' operands in flight together
             {
-                const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + cl;
-                const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + cl;
-                for (int i0 = 0; i0 < npend; i0 += 8) {
-                    double2 kk[8], gg[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int64_t so = (int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2;
-                        kk[q] = kp[so]; gg[q] = gp[so];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const double2 gl = make_double2(__shfl_xor(gg[q].x, 1), __shfl_xor(gg[q].y, 1));   // the partner column's G_i
-                        if (i0 + q < npend) {
-                            dcc = rank2_apply(dcc, kk[q], gg[q]);
-                            dlo = rank2_apply(dlo, kk[q], gl);    // odd lanes: K_i(2k+1,:) G_i(:,2k)
-                        }
-                    }
-                }
-                // ... and this correction's own pair (ring position npend), from registers
+                // the column's diagonal entries carry the pending pairs already (before barrier B); now this correction's own pair (ring position npend), from registers
                 const double2 kn = make_double2(k0, k1), gn = make_double2(g[0], g[1]);
                 const double2 gl = make_double2(__shfl_xor(gn.x, 1), __shfl_xor(gn.y, 1));
                 dcc = rank2_apply(dcc, kn, gn);
@@ -1167,14 +1216,14 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             }
             // workgroup arg-min: butterflies, the four column wavefronts' winners through LDS (the helper wavefronts have left:
             // a barrier counts live wavefronts only), one entry per workgroup for the next launch's reduce_partials_wave
-            wave_argmin(ll, ix);
+            wave_argmin_sparse(ll, ix);
             if ((tid & 63) == 0) { na_ll[tid >> 6] = ll; na_ix[tid >> 6] = ix == INT64_MAX ? -1 : (int)ix; }
             __syncthreads();
             if (tid < 64) {
                 ll = tid < kGatherCols / 64 ? na_ll[tid] : INFINITY;
                 ix = (tid < kGatherCols / 64 && na_ix[tid] >= 0) ? (int64_t)na_ix[tid] : INT64_MAX;
                 if (ix == INT64_MAX) ll = INFINITY;
-                wave_argmin(ll, ix);
+                wave_argmin_sparse(ll, ix);
                 if (tid == 0) store_partial(dl.parts_out + blockIdx.x, ll, ix == INT64_MAX ? -1 : (int)ix, dl.seq_out);
             }
         }
@@ -1352,26 +1401,61 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
 // ---------------------------------------------------------------------------------------------------
 // association (Correspondence.m:49-87): one thread per landmark, block arg-min, then a one-block finish
 // ---------------------------------------------------------------------------------------------------
-template <typename TS>
+// kPredict: a recorded predict(u) (ekf_predict is lazy) is applied to what the lanes read -- pose, Prr and the strip columns,
+// through the same per-entry functions as k_predict -- AND written to the other state buffer (a.cur ^ 1): this launch is
+// k_predict and the association of the scan's first row in one (lane k owns landmark k's two strip columns either way), so
+// the correction that follows neither waits for a k_predict launch nor folds the predict into its own latency chain.
+template <typename TS, bool kPredict>
 __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArgs a, double *__restrict__ pos_cost,
                                                            double *__restrict__ sig_cost,
                                                            AssocDecision *partial, int *ticket, AssocDecision *__restrict__ decision,
-                                                           AssocHostPartial *host_partials, int seq, double *__restrict__ cand) {
+                                                           AssocHostPartial *host_partials, int seq, double *__restrict__ cand,
+                                                           PredictArgs pa) {
     __shared__ double sh_ll[kAssocBlock / 64];
     __shared__ int64_t sh_ix[kAssocBlock / 64];
+    __shared__ PredictSmall aps;
     const int tid = threadIdx.x;
     const int cur = a.cur;
     const int64_t k = (int64_t)blockIdx.x * kAssocBlock + tid;
     double ll = INFINITY;
     int64_t ix = INT64_MAX;
+    if (kPredict) {
+        // one lane per workgroup runs the 3x3 part (two sincos + 9 entries); the others have nothing to do before it anyway
+        if (tid < 64) {
+            // wavefront 0: the two sincos (pre-motion heading on even lanes, heading + u2 on odd ones) in ONE call, then lane 0 forms
+            // the entries -- predict_small's arithmetic with half of its sincos latency
+            const double pose[3] = { st.x[cur][0], st.x[cur][1], st.x[cur][2] };
+            const double2 sc_l = sincosd_ni((tid & 1) ? pose[2] + pa.u1 : pose[2]);
+            const double sn = lane_bcast(sc_l.x, 0), cs = lane_bcast(sc_l.y, 0), sn2 = lane_bcast(sc_l.x, 1), cs2 = lane_bcast(sc_l.y, 1);
+            if (tid == 0) {
+                double prr[9];
+                for (int i = 0; i < 9; ++i) prr[i] = st.prr[cur][i];
+                predict_finish(pose, prr, pa.u0, pa.u1, pa.C, sn, cs, sn2, cs2, aps);
+            }
+        }
+        __syncthreads();
+    }
     if (k < a.N) {
         const double *__restrict__ x = st.x[cur];
         const double *__restrict__ strip = st.strip[cur];
         const TS *__restrict__ tiles = (const TS *)st.tiles;
         const int64_t j = 2 * k;
         double pss[24];
-        for (int i = 0; i < 9; ++i) pss[i] = st.prr[cur][i];
+        for (int i = 0; i < 9; ++i) pss[i] = kPredict ? aps.prr[i] : st.prr[cur][i];
         for (int t = 0; t < 3; ++t) for (int b = 0; b < 2; ++b) pss[9 + 2 * t + b] = strip[t * st.ldm + j + b];
+        if (kPredict) {
+            double *__restrict__ sn = st.strip[cur ^ 1];
+            double *__restrict__ xn = st.x[cur ^ 1];
+            for (int b = 0; b < 2; ++b) {
+                predict_strip(pss[9 + b], pss[11 + b], pss[13 + b], aps.fa, aps.fb);
+                sn[j + b] = pss[9 + b]; sn[st.ldm + j + b] = pss[11 + b]; sn[2 * st.ldm + j + b] = pss[13 + b];
+                xn[3 + j + b] = x[3 + j + b];
+            }
+            if (k == 0) {
+                for (int i = 0; i < 9; ++i) { st.prr[cur ^ 1][i] = aps.prr[i]; st.small[12 + i] = aps.Q[i]; }
+                for (int i = 0; i < 3; ++i) xn[i] = aps.pose[i];
+            }
+        }
         // the 2x2 diagonal block lives in a diagonal tile; on another shard's tile the position cost is NaN
         // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
         const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
@@ -1403,7 +1487,7 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         } else {
             pss[15] = pss[16] = pss[17] = pss[18] = NAN;
         }
-        for (int i = 0; i < 3; ++i) pss[19 + i] = x[i];
+        for (int i = 0; i < 3; ++i) pss[19 + i] = kPredict ? aps.pose[i] : x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
         SmallSolve sol;
         solve_small(pss, a.z0, a.z1, a.R00, a.R01, a.R10, a.R11, sol);
@@ -1418,14 +1502,15 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
         // block it holds; the candidates of all shards meet in k_assoc_merge
         if (like <= a.s_thresh && (have_diag || !a.own_only)) { ll = like; ix = k; }                         // :78
     }
-    // Workgroup arg-min: wavefront butterflies (no barrier), the wavefronts' winners through LDS, one more butterfly in wavefront 0.
-    wave_argmin(ll, ix);
+    // Workgroup arg-min: per wavefront (ballot + readlane for the usual lone candidate, butterflies otherwise -- no barrier), the
+    // wavefronts' winners through LDS, once more in wavefront 0.
+    wave_argmin_sparse(ll, ix);
     if ((tid & 63) == 0) { sh_ll[tid >> 6] = ll; sh_ix[tid >> 6] = ix; }
     __syncthreads();
     if (tid < 64) {
         ll = tid < kAssocBlock / 64 ? sh_ll[tid] : INFINITY;
         ix = tid < kAssocBlock / 64 ? sh_ix[tid] : INT64_MAX;
-        wave_argmin(ll, ix);
+        wave_argmin_sparse(ll, ix);
     }
     if (host_partials) {
         // The HOST takes the arg-min over the workgroups' winners: ONE 16-byte store per workgroup into mapped host memory, payload
@@ -2027,13 +2112,15 @@ hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int6
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,
                             AssocDecision *partial, int *ticket, AssocDecision *decision, AssocHostPartial *host_partials, int seq,
-                            double *cand, int storage, hipStream_t s) {
+                            double *cand, int storage, hipStream_t s, const PredictArgs *fused_predict) {
     const int64_t grid = cdiv(a.N > 0 ? a.N : 1, kAssocBlock);
-    EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_associate<double>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_partials, seq, cand),
-        hipLaunchKernelGGL(k_associate<float>, dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, partial, ticket,
-                           decision, host_partials, seq, cand));
+    PredictArgs pa = {};
+    if (fused_predict) pa = *fused_predict;
+#define EKF_A(TS_, PRED_) hipLaunchKernelGGL((k_associate<TS_, PRED_>), dim3((unsigned)grid), dim3(kAssocBlock), 0, s, st, a, pos_cost, sig_cost, \
+                                             partial, ticket, decision, host_partials, seq, cand, pa)
+    if (storage == 0) { if (fused_predict) EKF_A(double, true); else EKF_A(double, false); }
+    else              { if (fused_predict) EKF_A(float, true); else EKF_A(float, false); }
+#undef EKF_A
     return hipGetLastError();
 }
 

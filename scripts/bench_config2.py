@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--async-flush", action="store_true", help="cfg.async_flush: the pass over P on a second stream")
     ap.add_argument("--check", action="store_true", help="replay the same inputs through the CPU oracle and compare")
     ap.add_argument("--kernel-timing", action="store_true",
                     help="bracket k_associate / k_gather with HIP events (adds ~2 us per launch: use for the per-kernel figures, not for "
@@ -44,7 +45,7 @@ def main():
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     N = args.landmarks
     _, run = make_run(N, 20260102, 2 + args.steps, policy="nearest", m=args.m)
-    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, device_assoc=(0 if args.host_decision else 2 if args.verified else 1 if args.waited else 3))
+    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=(0 if args.host_decision else 2 if args.verified else 1 if args.waited else 3))
     lm = Landmark('SYNTHETIC')
     t0 = time.perf_counter()
     for u, scan in run[:2]:                      # warm-up sweep: appends every landmark
@@ -89,7 +90,7 @@ def main():
            "n_gpus": 1, "steps": args.steps, "ms_per_iteration": dt / args.steps * 1e3, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "configs[1]: %d landmarks, unknown correspondence (EKF_SLAM_UC.m + Correspondence.m), F64; "
                                   "iteration = predict + measure() over the %d nearest landmarks" % (N, args.m),
-                      "deferred_batch": args.batch, "tile": args.tile, "warmup_sweep_s": t_sweep,
+                      "deferred_batch": args.batch, "async_flush": args.async_flush, "tile": args.tile, "warmup_sweep_s": t_sweep,
                       "device_association": ("host mirror" if args.host_decision else "device, verified after dispatch" if args.verified
                                              else "device, waited for" if args.waited else
                                              "device-resident loop: decision produced and consumed on the device, no host wait"),
