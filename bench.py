@@ -97,6 +97,41 @@ def cpu_baseline(N, x, s, d, U, steps, budget_s=20.0):
                       "restatement with OpenMP (oracle/ekf_structured.c), full n x n P" % (done, N)}
 
 
+def cpu_baseline_dense(N_target, seed, Rc, n_small=1000, steps=2):
+    """the LITERAL-DENSE restatement (oracle/ekf_dense.py: every eye(n), zeros(n), 5 x n selector and n x n x n
+    product of EKF_SLAM.m executed as written -- what the reference's MATLAB / MKL executes) timed at n_small landmarks on this
+    host's cores and extrapolated to N_target by n^3 (the step is dominated by the two n x n x n products of EKF_SLAM.m:47 and
+    the one of :145).  A reported figure beside the primary, structured baseline -- not a target."""
+    from oracle import ekf_dense as D
+    from oracle.ekf_structured import available_cores
+    w, x, s, d, U = make_state(n_small, seed)
+    n = 3 + 2 * n_small
+    e = D.EKF_SLAM()
+    e.x, e.P, e.s = x.copy(), np.diag(d) + U @ U.T, list(s)
+    st = make_steps(w, n_small, steps + 1, Rc)
+    e.predict(st[0][0]); e._correct(st[0][1], st[0][2], st[0][3] + 1)          # untimed: BLAS threads start, pages are touched
+    t0 = time.perf_counter()
+    for (u, z, R, k) in st[1:]:
+        e.predict(u)
+        e._correct(z, R, k + 1)
+    dt = (time.perf_counter() - t0) / steps
+    nt = 3 + 2 * N_target
+    scale = (nt / n) ** 3
+    return {"value": 1.0 / (dt * scale), "unit": "update-steps/s", "cores": available_cores(),
+            "kind": "literal-dense, extrapolated n^3",
+            "sample": "%d steps (1 predict + 1 correct) at %d landmarks through oracle/ekf_dense.py (NumPy/OpenBLAS, O(n^3) as the "
+                      "reference is written): %.3f s per step, x (%d/%d)^3 = %.0f for %d landmarks"
+                      % (steps, n_small, dt, nt, n, scale, N_target)}
+
+
+def git_blob_hash(path):
+    """`git hash-object` of a file, so that the committed summary a figure was taken from can be told from a stale copy."""
+    import hashlib
+    with open(path, "rb") as fh:
+        data = fh.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def load_committed_pmc(N, tile, pairs):
     """HBM bytes per downdate launch from the newest committed PMC summary (profiles/round*_downdate_pmc.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command) for exactly this launch shape, else None."""
@@ -112,7 +147,8 @@ def load_committed_pmc(N, tile, pairs):
             continue
         for leg in rec.get("legs", []):
             if leg.get("landmarks") == N and leg.get("tile") == tile and leg.get("batch") == pairs:
-                return {"file": os.path.relpath(path, ROOT), "pairs_per_launch": pairs, "landmarks": N, "tile": tile,
+                return {"file": os.path.relpath(path, ROOT), "git_blob": git_blob_hash(path), "pairs_per_launch": pairs,
+                        "landmarks": N, "tile": tile,
                         "kernel": leg.get("kernel"), "hbm_bytes_per_launch": leg.get("hbm_bytes_per_launch"),
                         "matrix_pipe_busy": leg.get("matrix_pipe_busy")}
     return None
@@ -156,6 +192,9 @@ def main():
     ap.add_argument("--async-flush", action="store_true",
                     help="every leg: run each pass over P on a second stream into a second tile store, beside the next gather / "
                          "exchange (cfg.async_flush; measured on one GPU: slower at every size, 5-40 %%: profiles/round2_tuning.md sweeps 21, 22)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="--gpus 1 only: run the SHARDED code path (row-panel extraction, RCCL all-gather on the library's own 1-rank "
+                         "communicator, sharded gather; cfg.force_sharded) -- the per-step fixed cost of a shard, measurable on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deferred", action="store_true")
     args = ap.parse_args()
@@ -221,11 +260,21 @@ def main():
 
     conditioning = {"steps": 0}
 
+    forced = bool(args.force_sharded) and world == 1
+    sharded = world > 1 or forced
+
     def run_leg(batch, nsteps, nwarm, lookahead=False):
         e = Engine(mode="known", capacity=N, tile=args.tile, device=device, rank=rank, world=world, batch=batch,
-                   async_flush=args.async_flush)
+                   async_flush=args.async_flush, force_sharded=1 if forced else 0)
         e.load_lowrank_state(x, s, d, U)
         transport = "none"
+        if forced:
+            import ctypes
+            raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+            if L.lib().ekf_comm_unique_id(raw) != 0:
+                sys.exit("bench.py: --force-sharded needs librccl (ekf_comm_unique_id failed)")
+            e.comm_init(raw.raw)                                  # ncclCommInitRank with one rank: no second transport behind it
+            transport = "rccl-native"
         if world > 1:
             from ekf_slam_amd.sharding import attach_communicator
             # nccl: the library's own RCCL communicator or an error (no silent second transport); gloo: the rehearsal path
@@ -235,7 +284,7 @@ def main():
             # `chunk` is a marshalled run (Engine.marshal_steps): per step the host only passes addresses -- the per-call
             # numpy / ctypes conversions of the plain methods cost more than a shard's GPU time per step at 8 GPUs
             m = chunk["m"]
-            if lookahead and world > 1 and batch > 1:
+            if lookahead and sharded and batch > 1:
                 # a host that knows which landmarks the next `batch` corrections touch fetches their base row-panels
                 # in ONE all-gather (ekf_prefetch_rows); the corrections then need no exchange of their own
                 for b0 in range(0, m, batch):
@@ -321,7 +370,7 @@ def main():
     dfr = look = None
     if batch:
         dfr = run_leg(batch, d_steps, d_warm)
-        if world > 1:
+        if sharded:
             try:
                 look = run_leg(batch, d_steps, d_warm, lookahead=True)
             except Exception as ex:  # noqa: BLE001 -- an argument / state error is raised identically on every rank: report, go on
@@ -348,8 +397,8 @@ def main():
                        "landmarks": N, "state_dim": n, "tile": args.tile, "storage": "f64",
                        "deferred_batch": 1,
                        "shard": "tile (I,J) on rank (I+J) mod %d" % world, "transport": head["transport"],
-                       "exchange": "none" if world == 1 else "one all-gather of the 2 x 2N row-panel per update-step",
-                       "backend": backend if world > 1 else "none",
+                       "exchange": "none" if not sharded else "one all-gather of the 2 x 2N row-panel per update-step",
+                       "backend": backend if sharded else "none", "force_sharded": forced,
                        "conditioning_steps": conditioning["steps"], "async_flush": bool(args.async_flush),
                        "state_finite": head["state_finite"],
                        # trace / sum / sum of squares of the final P (lower triangle): the same workload gives the same
@@ -372,6 +421,12 @@ def main():
                                                      "(ekf_prefetch_rows): one all-gather per batch" % batch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, x, s, d, U, steps[args.warmup:])
+            # SURVEY.md 8d asks for both restatements beside the GPU figure: [0] the primary above, [1] the literal-dense one
+            out["cpu_baselines"] = [out["cpu_baseline"], cpu_baseline_dense(N, seed, Rc)]
+        timed_s = head["ms_per_step"] * 1e-3 * args.steps
+        if args.steps < 256:
+            out["config"]["note"] = ("--steps %d: the timed region of the headline leg is %.3f s (< 0.2 s); the 1 280-step default "
+                                     "is the figure to quote" % (args.steps, timed_s))
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -169,7 +169,9 @@ class EKF_SLAM_UC(_EkfBase):
 
     def __init__(self, capacity=_DEFAULT_CAPACITY, **engine_kw):
         super().__init__(capacity, **engine_kw)
-        self.correspondence = Correspondence(.00000000001, 1000000000, 'EKF_SLAM_UC')
+        # EKF_SLAM_UC.m:16: Correspondence(.00000000001, 1000000000, 'EKF_SLAM_UC') -- the engine's defaults (ekf_config_default);
+        # s_cost / s_thresh given as engine keywords arrive here too, so that the property and the engine start out equal
+        self.correspondence = Correspondence(self._e.cfg.s_cost, self._e.cfg.s_thresh, 'EKF_SLAM_UC')
 
     def _push_params(self):
         """measure() associates with h.correspondence's cost / threshold (EKF_SLAM_UC.m:16,119): the property is public and

@@ -152,3 +152,74 @@ def test_ten_thousand_landmarks_eight_shards(oracle_lib):
             merged[hole] = b[hole]
         np.testing.assert_array_equal(merged, a)
     g.close(); one.close()
+
+
+def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
+    """BASELINE.json configs[4]'s shape on one GPU: 40 000 landmarks bulk-loaded, F32 tile storage / F64 solve, every step =
+    predict + append of one new landmark + one correction (streaming append), deferred batch 12 -- against the F64-tile engine
+    on the same inputs (the reference's arithmetic is F64 throughout, EKF_SLAM.m:141-145; the structured CPU oracle would need a
+    51 GB matrix and minutes per step at this size, and F64 tiles == oracle is what every other test of this file establishes).
+    Checked: x (all of it), the digests of P, the robot rows, sampled 6 x 6 blocks on and off the diagonal incl. the appended
+    rows, against the tolerance DESIGN.md section 5 states for F32 tiles (tests/test_f32_drift_gpu.py: 6e-8 * (4 + sqrt(passes)));
+    trace(P) non-increasing across a correction; the measured errors go to gpurun_out/ for profiles/round3_config5_1gpu.json."""
+    import json, os
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.world import World
+    N0, steps, batch = 40000, 96, 12
+    cap = N0 + steps
+    w = World(cap, 20260101 + 5)
+    rng = np.random.default_rng(77)
+    n0 = 3 + 2 * N0
+    x = np.concatenate([[0.0, 0.0, 0.0], w.landmarks[:N0].reshape(-1)])
+    d = rng.uniform(0.01, 0.1, n0)
+    U = rng.normal(0.0, 0.01, (n0, 8))
+    s = np.arange(1, N0 + 1.0)
+    e64 = Engine(mode="known", capacity=cap, storage="f64", batch=batch)
+    e32 = Engine(mode="known", capacity=cap, storage="f32", batch=batch)
+    assert e32.cfg.tile == 256 and e64.cfg.tile == 128
+    for e in (e64, e32):
+        e.load_lowrank_state(x, s, d, U)
+    Rc = [.01, 5.0]
+    traces = []
+    for t in range(steps):
+        u = w.step()
+        k = (t * 37) % N0
+        (_, r, b), = w.observe([k])
+        R = np.diag([r * Rc[0], b * Rc[1]])
+        for e in (e64, e32):
+            e.predict(u)
+            e.append(u, R, w.landmarks[N0 + t], N0 + t + 1)
+        if t == steps - 1:
+            traces.append(e32.digest()[0])                  # after predict + append, before the correction
+        for e in (e64, e32):
+            e.correct([r, b], R, k)
+    traces.append(e32.digest()[0])
+    assert traces[1] <= traces[0] * (1 + 1e-7)              # a correction never increases trace(P) (to float rounding of the tiles)
+    assert e32.N == e64.N == cap
+    passes = steps / batch + 2                              # + the two digests above
+    tol = 6e-8 * (4.0 + np.sqrt(passes))
+    n = 3 + 2 * cap
+    x32, x64 = e32.get_x(), e64.get_x()
+    assert np.isfinite(x32).all()
+    ex = rel_err(x32, x64)
+    d32, d64 = e32.digest(), e64.digest()
+    ed = float(np.max(np.abs(d32 - d64) / np.abs(d64)))
+    er = rel_err(e32.get_P_block(0, 0, 3, n), e64.get_P_block(0, 0, 3, n))
+    scale = float(np.abs(e64.get_P_block(3, 3, 64, 64)).max())          # max |P| over a corner of the landmark block: the tiles' scale
+    rng = np.random.default_rng(3)
+    eb = 0.0
+    corners = [(3, 3), (3 + 2 * 127, 3), (3 + 2 * 20000, 3 + 2 * 19999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * N0, 3 + 2 * 123),
+               (3 + 2 * (N0 + 50), 3 + 2 * (N0 + 49))] + [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(24)]
+    for r0, c0 in corners:
+        a, b64 = e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)
+        eb = max(eb, float(np.abs(a - b64).max() / scale))
+    rec = {"landmarks": [N0, cap], "update_steps": steps, "deferred_batch": batch, "passes_over_P": passes, "tolerance": tol,
+           "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er, "rel_err_sampled_blocks": eb,
+           "trace_before_after_last_correction": traces}
+    print("config 5 shape, F32 vs F64 tiles: %s" % json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_f32_vs_f64.json"), "w") as fh:
+            json.dump(rec, fh)
+    assert ex <= tol and ed <= tol and er <= tol and eb <= tol, rec
+    e64.close(); e32.close()

@@ -61,6 +61,76 @@ def test_class_surface_matches_reference_names():
     assert len(x3) == 13
 
 
+@pytest.mark.parametrize("device_assoc", [3, 0])
+def test_reassigned_association_properties_reach_the_engine(device_assoc):
+    """The reference's tunables are public, assignable properties (EKF_SLAM.m:14-16; EKF_SLAM_UC.m:16 `correspondence`): a run that
+    reassigns them MID-RUN -- a new Correspondence object with a signature threshold so tight that a re-observed landmark's noisy
+    signature no longer matches, later edited in place back to the default -- against oracle.ekf_dense.EKF_SLAM_UC given the same
+    reassignments.  With the threshold ignored (the round-2 mirror never forwarded it) the tight phase would append nothing."""
+    from ekf_slam_amd import slam
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle import ekf_dense as D
+    _, run = make_run(12, 77, 12, policy="all")
+    gpu = slam.EKF_SLAM_UC(capacity=40, tile=16, batch=4, device_assoc=device_assoc)
+    ref = D.EKF_SLAM_UC()
+    lg, lr = slam.Landmark('SYNTHETIC'), SyntheticLandmark()
+    for t, (u, scan) in enumerate(run):
+        if t == 4:
+            # signatures are the integers 1..12; shift what the "sensor" reports by 0.05: |d| = 0.05 passes the default test
+            # (d^2 / 1e-11 = 2.5e8 <= 1e9) and fails this one (2.5e8 > 1e8) -> every row becomes a new landmark
+            gpu.correspondence = slam.Correspondence(1e-11, 1e8, 'EKF_SLAM_UC')
+            ref.correspondence = D.Correspondence(1e-11, 1e8, 'EKF_SLAM_UC')
+        if t == 6:
+            gpu.correspondence.s_thresh = 1e9                    # edited in place, like a MATLAB property of a value object
+            ref.correspondence.s_thresh = 1e9
+        scan_t = [(wid, r, b) for (wid, r, b) in scan]
+        gpu.predict(u); ref.predict(u)
+        if 4 <= t < 6:
+            # the tight phase: the table must offer entries N+1, N+2, ... for the appends (EKF_SLAM_UC.m:123) -- use a source
+            # whose signatures are off by 0.05 and whose table grows with the state
+            obs_g = _shifted(lg, scan_t, gpu.x, 0.05, gpu._e.N)
+            obs_r = _shifted(lr, scan_t, ref.x, 0.05, len(ref.s))
+            gpu.measure(None, u, obs_g); ref.measure(None, u, obs_r)
+        else:
+            gpu.measure(scan_t, u, lg); ref.measure(scan_t, u, lr)
+        assert gpu._e.N == len(ref.s), t
+    assert gpu._e.N > 12                                         # the tight phase did append
+    np.testing.assert_array_equal(gpu.s, np.asarray(ref.s, dtype=float))
+    assert rel_err(gpu.x, ref.x) < REL and rel_err(gpu.P, ref.P) < REL
+    # the known-correspondence class carries s_cost / s_thresh as plain assignable properties (EKF_SLAM.m:14-16)
+    k = slam.EKF_SLAM(capacity=4, tile=16)
+    k.s_cost, k.s_thresh = 2.5, 7.0
+    assert (k.s_cost, k.s_thresh) == (2.5, 7.0) and (k._e.cfg.s_cost, k._e.cfg.s_thresh) == (2.5, 7.0)
+
+
+class _Shifted:
+    """A landmark_list whose observed signatures are off by `shift` and whose table holds one entry per possible new index."""
+
+    def __init__(self, rows, table):
+        self._rows = np.asarray(rows, dtype=float).reshape(-1, 3)
+
+        class _Obj:
+            pass
+        self.landmarkObj = _Obj()
+
+        class _E:
+            def __init__(self, index, loc):
+                self.index, self.loc = index, np.asarray(loc, dtype=float)
+        self.landmarkObj.landmark = [_E(i, l) for i, l in table]
+        self.landmarkObj.table = lambda: (np.array([e.index for e in self.landmarkObj.landmark], dtype=float),
+                                          np.array([e.loc for e in self.landmarkObj.landmark], dtype=float).reshape(-1, 2))
+
+    def getLandmark(self, laserdata, x):
+        return self._rows
+
+
+def _shifted(src, scan, x, shift, N):
+    rows = np.asarray(src.getLandmark(scan, x), dtype=float).reshape(-1, 3).copy()
+    rows[:, 2] += shift
+    table = [(N + 1 + q, (100.0 + q, -50.0 - q)) for q in range(len(rows))]      # entries for the indices the appends will ask for
+    return _Shifted(rows, table)
+
+
 def test_runslam_end_to_end_with_ransac_bookkeeping():
     """SLAM('EKF_SLAM') with Landmark('RANSAC') on the GPU -- the product's landmark-list bookkeeping fed with wall
     foot-points -- against the literal-dense oracle driven by a HAND-SCRIPTED trace of what that bookkeeping must output

@@ -156,7 +156,7 @@ def test_kat11_two_corrections_in_a_row_on_the_gpu(tile, batch):
 
 
 @pytest.mark.parametrize("tile,batch", _SHAPES)
-@pytest.mark.parametrize("device_assoc", [0, 1, 2])
+@pytest.mark.parametrize("device_assoc", [0, 1, 2, 3])
 def test_kat12_uc_measure_with_a_new_landmark_on_the_gpu(device_assoc, tile, batch):
     """EKF_SLAM_UC.measure through the reference-named class: row 1 corrects landmark 1, row 2 matches no signature and is
     appended with signature N+1 = 3 and the loc of the table entry whose index is 3, row 3 corrects landmark 2 on n = 9."""

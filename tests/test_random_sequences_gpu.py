@@ -54,8 +54,12 @@ def test_random_sequence(seed, oracle_lib, tmp_path):
     N0 = int(rng.integers(3, 70))
     cap = N0 + 12
     kw = dict(mode="uc", capacity=cap, tile=tile)
-    cfgd = ShardGroup(world, batch=batch, async_flush=asy, **kw) if world > 1 else Engine(batch=batch, async_flush=asy, **kw)
-    plain = Engine(batch=1, **kw)
+    # measure(): the configured engine in a random association mode (3 = the default device-resident loop: decision produced and
+    # consumed on the device), the plain engine always host-decided -- two independent routes to the same rows
+    assoc = int(rng.choice([3, 3, 1, 2, 0]))
+    cfgd = ShardGroup(world, batch=batch, async_flush=asy, **kw) if world > 1 else \
+        Engine(batch=batch, async_flush=asy, device_assoc=assoc, **kw)
+    plain = Engine(batch=1, device_assoc=0, **kw)
     ref = StructuredEKF(cap, "uc")
     x, P, s = _initial(N0, rng)
     for e in (cfgd, plain):
@@ -63,7 +67,7 @@ def test_random_sequence(seed, oracle_lib, tmp_path):
         e.set_state(x, P, s)
     ref.w_pos, ref.s_cost, ref.s_thresh = w_pos, 50.0, 1e9
     ref.set_state(x, P, s)
-    what = "seed %d: tile %d batch %d world %d async %s w_pos %g N0 %d" % (seed, tile, batch, world, asy, w_pos, N0)
+    what = "seed %d: tile %d batch %d world %d async %s w_pos %g N0 %d assoc %d" % (seed, tile, batch, world, asy, w_pos, N0, assoc)
 
     def obs_of(k):
         xe = plain.get_x()
