@@ -2,14 +2,20 @@
 10 000 update-steps, every one rounding each landmark-block entry it touches to float once per pass over P; the reference's
 arithmetic is F64 throughout, EKF_SLAM.m:141-145).  The dozen-step checks of tests/test_f32_storage_gpu.py say nothing about
 that, so this runs the F32-tile engine and the F64-tile engine (same GPU, same inputs: predict + correction, a streaming
-append every 10th step) side by side for 2 000 update-steps on a 2 000-landmark map, records the max-norm relative error of x
-and P every 250 steps, and asserts the bound that DESIGN.md section 5 states for configs[4]:
+append every 10th step) side by side for 2 000 update-steps on a 2 000-landmark map and records the max-norm relative error of
+x and P every 250 steps.
 
-    after K update-steps   rel err(P) <= 6e-8 * (4 + sqrt(number of passes over P)),   rel err(x) <= the same
+What it shows (profiles/round3_f32_drift.json): the error of P does NOT grow like a random walk of roundings (sqrt of the passes)
+but LINEARLY in the update-steps, at ~1.6e-9 per step, whether every step rewrites P or only every 12th.  It sits on large,
+rarely touched entries (the diagonal blocks of appended, not yet re-observed landmarks: ~17 against the bulk's 0.1): each
+correction lowers them by far less than half a float ulp, so rounding the tile back to float returns the old value and the
+decrements are lost one after the other (stagnation) -- a bias, not noise.  x, computed in F64 from F64 gains, stays 2 orders
+of magnitude better.  The bound asserted here, and stated for configs[4] in DESIGN.md section 5:
 
-(6e-8 = float's unit roundoff: one rounding per entry and pass, accumulating like a random walk; a pass = one update-step at
-batch 1, one per `batch` steps when deferred -- so the deferred mode is also the more accurate one).  1e-6 holds for the whole
-10 000-step run only with batch >= 12 (sqrt(834) * 6e-8 = 1.7e-6 bound, measured below it); batch 1 ends near 5e-6."""
+    after K update-steps   rel err(P) <= 6e-8 + 3e-9 K      rel err(x) <= 6e-8 + 2e-10 K      (max-norm, against F64 tiles)
+
+i.e. F32 tiles hold BASELINE.json's 1e-6 for ~300 update-steps, 6e-6 at 2 000 and 3e-5 over configs[4]'s full 10 000 -- the
+F64 tile store (25.6 GB at 40 k landmarks, well inside one MI355X's 288 GB) is the mode that meets 1e-6 at that length."""
 import json
 import os
 
@@ -26,8 +32,12 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def bound(passes):
-    return EPS32 * (4.0 + np.sqrt(passes))
+def bound_P(k):
+    return EPS32 + 3e-9 * k
+
+
+def bound_x(k):
+    return EPS32 + 2e-10 * k
 
 
 @pytest.mark.parametrize("batch", [1, 12])
@@ -63,15 +73,18 @@ def test_f32_tiles_drift_over_two_thousand_update_steps(batch):
         if (t + 1) % EVERY == 0:
             ex, eP = rel_err(e32.get_x(), e64.get_x()), rel_err(e32.get_P(), e64.get_P())      # get_P flushes both
             passes = (t + 1) if batch == 1 else (t + 1) / batch + (t + 1) // EVERY              # + the flush each read forces
-            log.append({"update_steps": t + 1, "passes": passes, "rel_err_x": ex, "rel_err_P": eP, "bound": bound(passes)})
-            assert ex <= bound(passes) and eP <= bound(passes), log[-1]
+            log.append({"update_steps": t + 1, "passes_over_P": passes, "rel_err_x": ex, "rel_err_P": eP,
+                        "bound_x": bound_x(t + 1), "bound_P": bound_P(t + 1)})
             worst_x, worst_P = max(worst_x, ex), max(worst_P, eP)
     assert e32.N == e64.N == N0 + STEPS // 10
     tr32, tr64 = e32.digest()[0], e64.digest()[0]
-    assert abs(tr32 - tr64) / abs(tr64) <= bound(log[-1]["passes"])
     print("f32 drift, batch %d: %s" % (batch, json.dumps(log)))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "f32_drift_batch%d.json" % batch), "w") as fh:
             json.dump({"landmarks": [N0, e32.N], "batch": batch, "log": log}, fh)
+    for rec in log:
+        assert rec["rel_err_x"] <= rec["bound_x"] and rec["rel_err_P"] <= rec["bound_P"], rec
+    assert abs(tr32 - tr64) / abs(tr64) <= bound_P(STEPS)
+    assert log[-1]["rel_err_P"] > 1e-6          # the point of the statement: 1e-6 does NOT hold at this length with F32 tiles
     e64.close(); e32.close()

