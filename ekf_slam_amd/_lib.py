@@ -57,6 +57,7 @@ SIGNATURES = {
     "ekf_measure": (_i32, [_vp, _dp, _i64, _dp, _dp, _dp, _i64]),
     "ekf_comm_unique_id": (_i32, [ctypes.c_char_p]),
     "ekf_comm_init": (_i32, [_vp, ctypes.c_char_p]),
+    "ekf_hint_next": (_i32, [_vp, _i64]),
     "ekf_correct_begin": (_i32, [_vp, _dp, _dp, _i64]),
     "ekf_correct_finish": (_i32, [_vp]),
     "ekf_prefetch_rows": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),

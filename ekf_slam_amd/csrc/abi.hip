@@ -147,6 +147,11 @@ struct ekf_handle {
     int64_t pf_slab = 0, pf_N = 0;
     std::vector<int64_t> pf_idx;
     double *pf_store = nullptr;    // world x batch x slab_cap
+    // the row-panel of landmark nx_idx, extracted by the last pass over P itself (ekf_hint_next + k_downdate_w<.., kNext>): valid while
+    // the tiles, the map size and the send area stay as that pass left them and nothing is pending
+    int64_t hint_idx = -1;         // ekf_hint_next: the landmark the NEXT ekf_correct will name
+    bool nx_valid = false;
+    int64_t nx_idx = -1, nx_N = 0;
     void *comm = nullptr;          // ncclComm_t
     KernelTimer timers[EKF_KERNEL_COUNT];
     std::vector<void *> allocs;
@@ -297,6 +302,7 @@ int32_t retire_inflight(ekf_handle *h) {
     h->nfrozen = 0;
     h->inflight = false;
     h->pf_valid = false;       // prefetched row-panels were base values of the old store
+    h->nx_valid = false;
     return EKF_OK;
 }
 
@@ -313,6 +319,19 @@ void next_pass_direction(ekf_handle *h) {
     h->st.tm.reverse = alternate ? (h->st.tm.reverse ^ 1) : 0;
 }
 
+int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
+    const int64_t nt = ekf_tiles_for(mm_rows, h->T);
+    const int64_t cmax = (nt + h->cfg.world - 1) / h->cfg.world;
+    return cmax * h->T * 2;
+}
+
+// Where a correction's row-panel is extracted to.  With the library's own communicator and its own buffers: straight into this
+// rank's segment of the receive area -- the all-gather is then IN PLACE (sendbuff == recvbuff + rank * count): no local copy inside
+// the collective, and with one rank nothing at all.  Caller-provided buffers / a host-run exchange keep the separate send area.
+double *corr_send(const ekf_handle *h, int64_t slab) {
+    return (h->comm && h->send == h->own_send && h->recv == h->own_recv) ? h->recv + (size_t)h->cfg.rank * (size_t)slab : h->send;
+}
+
 // apply ALL pending pairs to the tiles now, in place on the main stream: ONE pass over P for npend update-steps
 int32_t flush_pending(ekf_handle *h) {
     int32_t rc = retire_inflight(h);
@@ -321,15 +340,25 @@ int32_t flush_pending(ekf_handle *h) {
     rc = refresh_work(h);
     if (rc) return rc;
     next_pass_direction(h);
+    bool extracted = false;
+    const int64_t hint = h->hint_idx;
     {
+        // a sharded handle that was told which landmark the next correction names lets this pass extract that row-panel
+        NextRow nx = { -1, nullptr };
+        if (h->sharded && h->npend == 1 && !h->pending && hint >= 0 && hint < h->N) {
+            nx.j = 2 * hint;
+            nx.send = corr_send(h, slab_for(h, n_mm(h)));
+        }
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
         HIPCHK(h, launch_downdate(h->st, h->st.tiles, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart, h->npend,
-                                  h->storage, h->grid_cap, h->stream, h->dd_kernel));
+                                  h->storage, h->grid_cap, h->stream, h->dd_kernel, nx.j >= 0 ? &nx : nullptr, &extracted));
         h->dd_pairs = h->npend;
     }
     h->npend = 0;
     h->pstart = 0;
     h->pf_valid = false;       // the prefetched row-panels were base values of the old tiles
+    h->nx_valid = extracted;
+    if (extracted) { h->nx_idx = hint; h->nx_N = h->N; }
     return EKF_OK;
 }
 
@@ -472,13 +501,8 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     h->s_host.push_back(signature);
     h->N += 1;
     h->pf_valid = false;
+    h->nx_valid = false;
     return EKF_OK;
-}
-
-int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
-    const int64_t nt = ekf_tiles_for(mm_rows, h->T);
-    const int64_t cmax = (nt + h->cfg.world - 1) / h->cfg.world;
-    return cmax * h->T * 2;
 }
 
 constexpr int kThrottle = 48;
@@ -501,6 +525,7 @@ int32_t finish_step(ekf_handle *h) {
     h->cur ^= 1;
     h->npend += 1;
     const int32_t rc = (h->npend - h->nfrozen) >= h->batch ? batch_complete(h) : EKF_OK;
+    h->hint_idx = -1;          // a hint speaks of the correction that follows THIS one only
     if (rc) return rc;
     return throttle_step(h);
 }
@@ -525,8 +550,13 @@ int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64
     if (rc) return rc;
     fill_correct_args(h, h->pending_args, z, R, idx);
     h->slab = slab_for(h, h->pending_args.n_mm);
-    HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->pstart, h->npend, h->send, h->storage,
-                              h->stream));
+    if (h->nx_valid && h->nx_idx == idx && h->nx_N == h->N && h->npend == 0) {
+        // the last pass over P left this row-panel in the send area (ekf_hint_next): nothing to extract
+    } else {
+        HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->pstart, h->npend, corr_send(h, h->slab), h->storage,
+                                  h->stream));
+    }
+    h->nx_valid = false;
     h->pending = true; h->pending_kind = 1; h->x_count = h->slab;
     return EKF_OK;
 }
@@ -554,6 +584,8 @@ int32_t prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
     const int64_t slab = slab_for(h, n_mm(h));
     HIPCHK(h, launch_rowpanel_base(h->st, idx, m, n_mm(h), h->send, slab, h->storage, h->stream));
     h->pf_valid = false;
+    h->nx_valid = false;
+    h->nx_valid = false;       // (a prefetch's all-gather overwrites the receive area the extracted panel sits in)
     h->pf_idx.assign(idx, idx + m);
     h->pf_m = m; h->pf_slab = slab; h->pf_N = h->N;
     h->pending = true; h->pending_kind = 2; h->x_count = (int64_t)m * slab;
@@ -573,7 +605,8 @@ int32_t exchange_rccl(ekf_handle *h) {
     REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
             "sharded handle without a communicator: call ekf_comm_init, or drive the begin / your own all-gather / "
             "finish calls");
-    const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
+    const double *src = h->pending_kind == 1 ? corr_send(h, h->x_count) : h->send;
+    const int r = g_rccl.AllGather(src, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
     if (r != 0) { h->pending = false; return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r)); }
     return EKF_OK;
 }
@@ -732,6 +765,7 @@ int32_t assoc_begin(ekf_handle *h, const double z[3], const double R[4], bool wa
     const int32_t rc = launch_assoc(h, z, R, nullptr, 0, /*exchange*/ true, want_costs);
     if (rc) return rc;
     h->pending = true; h->pending_kind = 3; h->x_count = 4 + (want_costs ? h->N : 0);
+    h->nx_valid = false;       // (the candidates' all-gather overwrites the receive area)
     h->assoc_costs = want_costs;
     return EKF_OK;
 }
@@ -1211,6 +1245,8 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
                 if (rc) return rc;
                 rc = do_append(h, u, R, loc, z[2]);
             } else {
+                // a shard that rewrites P per correction lets this row's pass extract the next row's panel (ekf_hint_next)
+                if (h->sharded && h->batch == 1 && ii + 1 < m && !(obs[2 * m + ii + 1] > (double)h->N) && ii + 1 < h->N) h->hint_idx = ii + 1;
                 rc = do_correct(h, z, R, ii);                              // :123  idx = ii
             }
         } else if (dev_loop) {
@@ -1285,6 +1321,12 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
         if (rc) { verify_speculated(h); return rc; }
     }
     return verify_speculated(h);
+}
+
+int32_t ekf_hint_next(ekf_handle *h, int64_t idx) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    h->hint_idx = (idx >= 0 && idx < h->N) ? idx : -1;
+    return EKF_OK;
 }
 
 int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
@@ -1457,6 +1499,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     }
     h->N = (n - 3) / 2;
     h->pf_valid = false;       // a prefetch belongs to the state it was taken from
+    h->nx_valid = false;
     h->s_host.resize((size_t)h->N, 0.0);
     HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1508,6 +1551,7 @@ int32_t ekf_set_P(ekf_handle *h, const double *P, int64_t n) {
     { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
     h->npend = 0; h->pstart = 0;   // the whole covariance is replaced ...
     h->pf_valid = false;           // ... and with it every prefetched base row-panel
+    h->nx_valid = false;
     double *dense = nullptr;
     HIPCHK(h, hipMalloc((void **)&dense, (size_t)(n * n) * 8));
     hipError_t e = hipMemcpyAsync(dense, P, (size_t)(n * n) * 8, hipMemcpyHostToDevice, h->stream);
@@ -1580,6 +1624,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
     h->npend = 0; h->pstart = 0;   // the whole state is replaced ...
     h->pf_valid = false;           // ... and with it every prefetched base row-panel
+    h->nx_valid = false;
     rc = refresh_work(h);
     if (rc) return rc;
     double *dd = nullptr, *dU = nullptr;
@@ -1689,7 +1734,7 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     if (hipHostMalloc(&stage, stage_bytes, hipHostMallocDefault) != hipSuccess) { stage = nullptr; return done(fail(h, EKF_ERR_HIP, "checkpoint: staging buffer")); }
     rc = retire_inflight(h);
     if (rc) return done(rc);
-    h->npend = 0; h->pstart = 0; h->pf_valid = false; h->have_pp = false;
+    h->npend = 0; h->pstart = 0; h->pf_valid = false; h->nx_valid = false; h->have_pp = false;
     hipError_t e = hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
     if (e != hipSuccess) return done(fail(h, EKF_ERR_HIP, "checkpoint_load: clearing the pending pairs", e));

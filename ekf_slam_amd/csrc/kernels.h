@@ -154,8 +154,13 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // dst: tile store the result is written to (== st.tiles for an in-place flush; a second buffer for the asynchronous
 // flush, which must not disturb kernels still reading st.tiles); pstart: ring slot of the first pair
 // kname: nullptr, or 64 bytes that receive the name of the kernel instance that was launched ("k_flush_mfma<double,128,8>")
+// nx (sharded handles; nullptr or j < 0: none): ALSO extract the row-panel of landmark-block rows nx->j, nx->j + 1 into nx->send (layout
+// of launch_rowpanel) from the updated entries; *extracted tells whether the instance that was launched did it (one pair per
+// launch, wavefront-per-row tile shapes only)
+struct NextRow { int64_t j; double *send; };
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname);
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx = nullptr,
+                           bool *extracted = nullptr);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries; ticket: a
 // device int, zero between launches (the last workgroup to finish reduces the partials and resets it: one launch, no
 // finishing kernel); decision: device copy.  host_partials != nullptr (mapped host memory, one entry per workgroup): NO cross-workgroup

@@ -1327,11 +1327,52 @@ __device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
     t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
 }
 
-template <typename TS, int T, int kSlab, bool kXcd>
+// Out of line on purpose: the pass is HBM-bound to the last per cent, and with this code inlined its main body was scheduled 8 %
+// slower (551 vs 510 us at 10 k landmarks) although only two tile lines in ~150 ever come here.
+// M = P(j:j+1, :) as k_rowpanel lays it out: chunk k of T columns comes from tile (I_j, k) for k <= I_j (rows j, j+1 of the tile:
+// M(a, c) = P(j+a, c)) and from tile (k, I_j) beyond (columns j, j+1 of the tile: M(a, c) = P(c, j+a)); on the diagonal tile the
+// lower triangle is canonical: M(1, j+1) = P(j+1, j).  Local chunk kl = (k - k0) / world.
+__device__ __attribute__((noinline)) void extract_next_row(double *__restrict__ send, int jm, int Ij, int tI, int tJ, int r, int c0, int ncols,
+                                                           int T, int world, int rank, double v0, double v1, double v2, double v3) {
+    const uint32_t wd = (uint32_t)world;
+    const int k0 = (int)(((uint32_t)rank + wd - (uint32_t)Ij % wd) % wd);
+    const bool rowtile = tI == Ij, coltile = tJ == Ij, diag = rowtile && coltile;
+    for (int q = 0; q < ncols; ++q) {
+        const int cc = c0 + q;                                      // tile column
+        const double val = q == 0 ? v0 : q == 1 ? v1 : q == 2 ? v2 : v3;
+        if (rowtile && (r == jm || r == jm + 1)) {
+            const int a = r - jm;
+            if (!diag || cc <= jm) {                                // c <= j: M(a, c) = P(j + a, c)
+                const int64_t e = (int64_t)((tJ - k0) / world) * T + cc;
+                send[2 * e + a] = val;
+            }
+            if (diag && a == 1 && (cc == jm || cc == jm + 1)) {     // canonical (j+1, j) = M(1, j+1); (j+1, j+1) = M(2, j+1)
+                const int64_t e = (int64_t)((Ij - k0) / world) * T + jm + 1;
+                send[2 * e + (cc - jm)] = val;
+            }
+        }
+        if (coltile && (cc == jm || cc == jm + 1) && (tI > Ij || r > jm + 1)) {     // c = I T + r >= j + 2: M(a, c) = P(c, j + a)
+            const int64_t e = (int64_t)((tI - k0) / world) * T + r;
+            send[2 * e + (cc - jm)] = val;
+        }
+    }
+}
+
+// kNext (sharded handles, one pair per launch, the NEXT correction's landmark announced: ekf_hint_next): the pass also EXTRACTS the
+// row-panel P(j:j+1, :) of that landmark into the exchange slab while the updated entries are in registers -- the workgroups
+// that own rows j, j+1 of tile row I_j write the row part, those of tile column I_j the column part; what they write is what
+// k_rowpanel would read back from the tiles a launch later (canonical lower-triangle entries, after the rounding to TS).  The
+// next update-step then starts with its all-gather: one launch (~5 us of a shard's fixed cost) less.
+struct NoNextRow {};
+template <bool kNext> struct NextRowParam { using type = NoNextRow; };
+template <> struct NextRowParam<true> { using type = NextRow; };
+
+template <typename TS, int T, int kSlab, bool kXcd, bool kNext = false>
 __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ tiles, TS *__restrict__ dst,
                                                        const int2 *__restrict__ work, int64_t nwork,
                                                        const double *__restrict__ Kp, const double *__restrict__ Gp,
-                                                       int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm) {
+                                                       int64_t pair_stride, int pstart, int pcap, int npairs, TileMap tm,
+                                                       typename NextRowParam<kNext>::type nx) {
     using VL = typename Lane16<TS>::type;
     constexpr int kCols = Lane16<TS>::kCols;              // columns per lane: 2 (f64 tiles) or 4 (f32 tiles)
     constexpr int kLanesPerRow = T / kCols;               // 64: one row per wave instruction; 32: two rows
@@ -1393,6 +1434,19 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
             VL o;
             lane16_pack(v[p], o);
             *reinterpret_cast<VL *>(td + (int64_t)p * kRowsPerInstr * T) = o;
+        }
+        if constexpr (kNext) {
+            const int Ij = (int)(nx.j >> tm.shift);
+            if (__builtin_expect(ij.x == Ij || ij.y == Ij, 0)) {        // uniform per workgroup; two tile lines out of nt
+#pragma unroll
+                for (int p = 0; p < kPasses; ++p) {
+                    double vv[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int q = 0; q < kCols; ++q) vv[q] = (double)(TS)v[p][q];   // what the tile now holds
+                    extract_next_row(nx.send, (int)(nx.j & (T - 1)), Ij, ij.x, ij.y, row0 + sub + p * kRowsPerInstr, kCols * cl, kCols, T,
+                                     tm.world, tm.rank, vv[0], vv[1], vv[2], vv[3]);
+                }
+            }
         }
     }
 }
@@ -2036,7 +2090,8 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
 
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
-                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname) {
+                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname,
+                                     const NextRow *nx, bool *extracted) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = ekf_tune_int("EKF_FLUSH_XCD", 1) != 0;
     if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)) return hipGetLastError();
@@ -2045,13 +2100,20 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
             int64_t grid = 8 * xcd_len * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
             hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
-                               (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                               (TS *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm, NoNextRow{});
             name_kernel(kname, "k_downdate_w", sizeof(TS), T, kSlab, 1);
+        } else if (nx && nx->j >= 0 && npairs == 1) {
+            int64_t grid = nwork * (T / kSlab);
+            if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+            hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
+                               (TS *)dstv, work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm, *nx);
+            if (kname) snprintf(kname, 64, "k_downdate_w<%s,%d,%d,false,+rowpanel>", sizeof(TS) == 8 ? "double" : "float", T, kSlab);
+            if (extracted) *extracted = true;
         } else {
             int64_t grid = nwork * (T / kSlab);
             if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
             hipLaunchKernelGGL((k_downdate_w<TS, T, kSlab, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles,
-                               (TS *)dstv, work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                               (TS *)dstv, work, nwork, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm, NoNextRow{});
             name_kernel(kname, "k_downdate_w", sizeof(TS), T, kSlab, 0);
         }
     } else {
@@ -2073,10 +2135,11 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
 // K wave-uniform); T = 16 / 32 (generic kernel) and T = 64 exist for small maps and tests.
 template <typename TS>
 static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
-                                    int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s, char *kname) {
+                                    int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s, char *kname,
+                                    const NextRow *nx, bool *extracted) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, nx, extracted)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -2102,12 +2165,14 @@ static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *
 }
 
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
-                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname) {
+                           int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx,
+                           bool *extracted) {
+    if (extracted) *extracted = false;
     static const int slab1 = ekf_tune_int("EKF_DOWNDATE_SLAB", 0);
     static const int slabm = ekf_tune_int("EKF_DOWNDATE_SLAB_BATCH", 0);
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname)
-                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname);
+    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted)
+                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

@@ -44,6 +44,7 @@ class Engine:
                 setattr(cfg, k, v)
         self.cfg = cfg
         self._host_exchange = None
+        self._hints = False
         self._raw = None
         self.h = ctypes.c_void_p()
         rc = self.lib.ekf_create(ctypes.byref(cfg), ctypes.byref(self.h))
@@ -91,16 +92,19 @@ class Engine:
         if self._raw is None:
             proto_p = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
             proto_c = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+            proto_h = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64)
             self._raw = (proto_p(("ekf_predict", self.lib)), proto_c(("ekf_correct", self.lib)),
-                         proto_c(("ekf_correct_begin", self.lib)))
+                         proto_c(("ekf_correct_begin", self.lib)), proto_h(("ekf_hint_next", self.lib)))
         return {"U": U, "Z": Z, "R": Rm, "K": K, "k": K.tolist(), "u": U.ctypes.data, "z": Z.ctypes.data, "r": Rm.ctypes.data, "m": m}
 
     def step_raw(self, run, i):
         """predict(u_i) + correct(z_i, R_i, idx_i) of a marshalled run."""
-        f_pred, f_corr, f_begin = self._raw
+        f_pred, f_corr, f_begin, f_hint = self._raw
         rc = f_pred(self.h, run["u"] + 16 * i)
         if rc:
             self._check(rc)
+        if self._hints and i + 1 < run["m"]:     # sharded, library-owned communicator, batch 1: announce the next landmark
+            f_hint(self.h, run["k"][i + 1])
         if self._host_exchange is not None:
             rc = f_begin(self.h, run["z"] + 16 * i, run["r"] + 32 * i, run["k"][i])
             if rc:
@@ -162,6 +166,10 @@ class Engine:
     def comm_init(self, comm_id_bytes):
         assert len(comm_id_bytes) == L.EKF_COMM_ID_BYTES
         self._check(self.lib.ekf_comm_init(self.h, bytes(comm_id_bytes)))
+        self._hints = self.cfg.batch <= 1 and not self.cfg.async_flush      # step_raw announces the next landmark (ekf_hint_next)
+
+    def hint_next(self, idx0):
+        self._check(self.lib.ekf_hint_next(self.h, int(idx0)))
 
     def associate(self, z, R, want_costs=False):
         if self._host_exchange is not None and (want_costs or self.cfg.w_pos != 0.0):

@@ -139,6 +139,11 @@ class ShardGroup:
         for e in self.shards:
             e.correct_finish()
 
+    def hint_next(self, idx0):
+        """The landmark the NEXT correct() names (ekf_hint_next): the current correction's pass extracts its row-panel."""
+        for e in self.shards:
+            e.hint_next(idx0)
+
     def prefetch_rows(self, idx0_list):
         for e in self.shards:
             e.prefetch_begin(idx0_list)

@@ -171,6 +171,13 @@ int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, doubl
 int32_t ekf_measure(ekf_handle *h, const double *observed_LL, int64_t m, const double u[2],
                     const double *lm_index, const double *lm_loc, int64_t L);
 
+/* Sharded handles, cfg.batch = 1 (every correction rewrites P at once): tell the handle which
+ * landmark (0-based) the NEXT ekf_correct will name.  The pass over P that ends the current correction then also extracts that
+ * landmark's row-panel into the exchange area (its entries are in registers anyway), so the next update-step starts with its
+ * all-gather instead of an extraction launch (with the library's own communicator and buffers that all-gather runs in place).  A hint holds for one correction; a wrong or
+ * missing one only costs the extraction launch back.  Results are bit-identical either way.  No-op on other handles. */
+int32_t ekf_hint_next(ekf_handle *h, int64_t idx);
+
 /* ---- multi-GPU: P split over `world` shards (cfg.rank / cfg.world), tile (I,J) on shard (I+J) mod world ----
  * x, s, the robot block and the robot/landmark strip are replicated; predict, append and associate need no
  * exchange.  A correction needs the 2 x 2N landmark row-panel P(j:j+1,:), whose T-wide chunk k lives on shard

@@ -34,7 +34,8 @@ def main():
     steps = bench.make_steps(w, N, 64 + a.steps, [.01, 5.0])
     out = {"landmarks": N, "steps": a.steps, "batch": a.batch}
     digests = []
-    legs = [("unsharded", "0", False), ("sharded_1rank_rccl", "1", False)]
+    # "_nohint": the sharded leg without ekf_hint_next (round 2's flow: k_rowpanel launch per step; the all-gather is in place either way)
+    legs = [("unsharded", "0", False), ("sharded_1rank_rccl", "1", False), ("sharded_1rank_rccl_nohint", "1", False)]
     if a.async_flush:
         legs += [("unsharded_async", "0", True), ("sharded_1rank_rccl_async", "1", True)]
     for name, forced, asy in legs:
@@ -43,6 +44,8 @@ def main():
             raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
             assert L.lib().ekf_comm_unique_id(raw) == 0
             e.comm_init(raw.raw)
+            if name.endswith("_nohint"):
+                e._hints = False
         e.load_lowrank_state(x, s, d, U)
         warm, timed = e.marshal_steps(steps[:64]), e.marshal_steps(steps[64:])
         for i in range(warm["m"]):
@@ -57,6 +60,7 @@ def main():
         digests.append(e.digest())
         e.close()
     out["extra_us_per_step"] = round((out["sharded_1rank_rccl"]["ms_per_step"] - out["unsharded"]["ms_per_step"]) * 1e3, 2)
+    out["extra_us_per_step_nohint"] = round((out["sharded_1rank_rccl_nohint"]["ms_per_step"] - out["unsharded"]["ms_per_step"]) * 1e3, 2)
     out["same_digest"] = all(bool(np.array_equal(digests[0], dg)) for dg in digests[1:])
     print(json.dumps(out), flush=True)
 

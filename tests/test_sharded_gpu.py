@@ -342,3 +342,55 @@ def test_measure_is_refused_up_front_on_a_shard_without_communicator():
     assert g.shards[0].N == N
     np.testing.assert_array_equal(g.shards[0].get_x(), x0)
     g.close()
+
+
+@pytest.mark.parametrize("world,tile,storage", [(2, 128, "f64"), (3, 64, "f64"), (4, 128, "f64"), (8, 64, "f64"), (2, 128, "f32"), (1, 128, "f64")])
+def test_hinted_pass_extracts_the_next_row_panel(world, tile, storage):
+    """ekf_hint_next: with cfg.batch = 1 the pass over P that ends a correction also extracts the row-panel of the landmark the
+    NEXT correction names (k_downdate_w<..., +rowpanel>), so that step starts with its exchange.  Right hints, wrong hints, no
+    hint, a hint overtaken by an append, landmarks on the first / last rows of tiles and of the map: the state must equal the
+    unsharded engine's bit for bit throughout, and the extraction must actually have been the launched instance."""
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    N = 200
+    x, P, s, _, _ = _state(N, 91)
+    kw = dict(capacity=N + 4, tile=tile, storage=storage, batch=1)
+    g = ShardGroup(world, **kw) if world > 1 else None
+    if g is None:
+        import ctypes
+        from ekf_slam_amd import _lib as L
+        g1 = Engine(force_sharded=1, **kw)
+        raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+        assert L.lib().ekf_comm_unique_id(raw) == 0
+        g1.comm_init(raw.raw)                    # 1-rank RCCL communicator: the in-place all-gather of the library's own transport
+    one = Engine(**kw)
+    for e in ([g] if g else [g1]) + [one]:
+        e.set_state(x, P, s)
+    sh = g if g else g1
+    first = g.shards[0] if g else g1
+    rng = np.random.default_rng(5)
+    T2 = tile // 2                               # landmarks per tile row
+    seq = [0, 1, T2 - 1, T2, T2 + 1, N - 1, 0, 2 * T2 - 1, 2 * T2, 77, 77, N - 1, N - 2, 5] + [int(v) for v in rng.integers(0, N, 20)]
+    used = 0
+    for t, k in enumerate(seq):
+        z = [float(rng.uniform(1, 30)), float(rng.uniform(1, 359))]
+        R = np.array([[z[0] * .01, 0.001], [0.001, z[1] * 5.0]])
+        nxt = seq[t + 1] if t + 1 < len(seq) else None
+        mode = t % 5
+        if nxt is not None and mode in (0, 1, 2):
+            sh.hint_next(nxt)                    # right hint
+        elif nxt is not None and mode == 3:
+            sh.hint_next((nxt + 3) % N)          # wrong hint: the extraction is wasted, k_rowpanel runs as usual
+        sh.predict([0.1, 2.0]); one.predict([0.1, 2.0])
+        sh.correct(z, R, k); one.correct(z, R, k)
+        if nxt is not None and mode in (0, 1, 2, 3):
+            assert "+rowpanel" in first.downdate_kernel_name()[0], first.downdate_kernel_name()
+            used += 1
+        if t == 9:                               # an append between a hinted pass and the correction it was for
+            pos = rng.uniform(-5, 5, 2)
+            sh.append([0.1, 2.0], R, pos, N + 1); one.append([0.1, 2.0], R, pos, N + 1)
+        np.testing.assert_array_equal(sh.get_x(), one.get_x(), err_msg="step %d" % t)
+    assert used > 20
+    Ps = sh.get_P()
+    np.testing.assert_array_equal(Ps, one.get_P())
+    sh.close(); one.close()
