@@ -101,6 +101,7 @@ def attach_communicator(engine, dist, torch, transport="rccl"):
                 dist.all_gather_into_tensor(recv[:cnt * world], send[:cnt])
 
     engine._host_exchange = host_exchange
+    engine._hints = engine.cfg.batch <= 1 and not engine.cfg.async_flush     # step_raw announces the next landmark (ekf_hint_next)
     return "torch.distributed" if not staged else "torch.distributed(%s, host-staged)" % dist.get_backend()
 
 

@@ -5,11 +5,14 @@ set -e -o pipefail
 TAG=${1:-r2q}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-# configs[1]: device association in the loop (primary), host-decided second; per-kernel figures from a separate timed run
-python scripts/bench_config2.py --check > $OUT/config2_device.json 2>/dev/null
-python scripts/bench_config2.py --host-decision > $OUT/config2_host.json 2>/dev/null
-python scripts/bench_config2.py --kernel-timing > $OUT/config2_device_timed.json 2>/dev/null
-python scripts/bench_config2.py --batch 1 > $OUT/config2_device_b1.json 2>/dev/null
+# configs[1]: the device-resident loop (cfg.device_assoc = 3, the default) is the primary; the other three modes beside it
+python scripts/bench_config2.py --check > $OUT/config2_devloop.json 2>/dev/null
+python scripts/bench_config2.py --batch 1 --check > $OUT/config2_devloop_b1.json 2>/dev/null
+python scripts/bench_config2.py --batch 16 > $OUT/config2_devloop_b16.json 2>/dev/null
+python scripts/bench_config2.py --verified --check > $OUT/config2_verified.json 2>/dev/null
+python scripts/bench_config2.py --waited --check > $OUT/config2_waited.json 2>/dev/null
+python scripts/bench_config2.py --host-decision --check > $OUT/config2_host.json 2>/dev/null
+bash scripts/trace_config2.sh $TAG/c2trace --batch 8 > /dev/null
 # configs[4] shape on one GPU: 40 k landmarks F32 tiles, streaming append; immediate, batch 12, batch 32; the full 50 k map
 python scripts/bench_config5.py --batch 1 --steps 96 --warmup 16 > $OUT/config5_40k_b1.json 2>/dev/null
 python scripts/bench_config5.py --batch 12 --steps 384 > $OUT/config5_40k_b12.json 2>/dev/null
