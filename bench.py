@@ -185,8 +185,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--landmarks", type=int, default=10000)
     ap.add_argument("--tile", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=32,
-                    help="corrections per pass over P in the `deferred` leg (0 / 1: skip that leg)")
+    ap.add_argument("--batch", type=int, default=20,
+                    help="corrections per pass over P in the `deferred` leg (0 / 1: skip that leg).  20: the pass stays above 0.70 of the "
+                         "HBM roofline with margin (0.554 ms, 0.72; 24 pairs: 0.57 ms, 0.69-0.70 depending on the box); from 28 pairs on it "
+                         "is co-limited by the f64 pipe (32: 0.63 ms, 0.64) for ~20 %% more update-steps/s -- DESIGN.md 3b")
     ap.add_argument("--deferred-steps", type=int, default=0,
                     help="timed steps of the deferred legs (default: 40 batches; always whole batches)")
     ap.add_argument("--async-flush", action="store_true",

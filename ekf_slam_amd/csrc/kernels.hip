@@ -1946,7 +1946,7 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // for every x, signed zeros included).
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// Two chunk sizes: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~24 pairs, where the pass is
+// Two chunk sizes: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~30 pairs (28 pairs: 0.603 vs 0.634 ms; 32: 0.651 vs 0.627), where the pass is
 // HBM-bound and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond,
 // where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
 // Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
@@ -2067,7 +2067,7 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
     constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
     if constexpr (kHave) {
         static const bool use_mfma = ekf_tune_int("EKF_FLUSH_MFMA", 1) != 0;
-        static const int chunk_switch = ekf_tune_int("EKF_FLUSH_MFMA_SWITCH", 26);
+        static const int chunk_switch = ekf_tune_int("EKF_FLUSH_MFMA_SWITCH", 30);
         // F32 tiles: also for a single pair -- the 64 x 128 work items stream the float tiles faster than the one-pair VALU kernel
         // (40 k landmarks: 4.4 ms vs 4.9 ms per pass); F64 tiles: the one-pair VALU kernel is the faster one (0.53 vs 0.56 ms)
         constexpr int kMinPairs = sizeof(TS) == 4 ? 1 : 2;

@@ -44,14 +44,14 @@ def test_launcher_and_gpus_must_agree():
 
 def test_committed_pmc_summary_covers_the_default_bench_shapes():
     """`roofline.traffic` of the default `python bench.py` comes from the newest committed PMC summary for exactly the launch shape
-    that ran (bench.load_committed_pmc); the default run launches the one-pair pass and the 32-pair flush at 10 000 landmarks,
+    that ran (bench.load_committed_pmc); the default run launches the one-pair pass and the 20-pair flush at 10 000 landmarks,
     tile 128 -- both must be in profiles/, name the kernel the launcher reports, and hold traffic within a few per cent of the
     algorithmic bytes (a stale or missing summary would silently turn `traffic` into null)."""
     sys.path.insert(0, ROOT)
     import bench
     n = 3 + 2 * 10000
     b_alg = 8 * n * (n + 1)
-    for pairs, kernel in ((1, "k_downdate_w"), (32, "k_flush_mfma")):
+    for pairs, kernel in ((1, "k_downdate_w"), (20, "k_flush_mfma")):
         rec = bench.load_committed_pmc(10000, 128, pairs)
         assert rec is not None, "no committed PMC summary for %d pair(s) per launch" % pairs
         assert rec["kernel"] and kernel in rec["kernel"]
