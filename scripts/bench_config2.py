@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--no-conditioning", action="store_true", help="skip the untimed device-conditioning replay on a throw-away engine")
     ap.add_argument("--async-flush", action="store_true", help="cfg.async_flush: the pass over P on a second stream")
     ap.add_argument("--check", action="store_true", help="replay the same inputs through the CPU oracle and compare")
     ap.add_argument("--kernel-timing", action="store_true",
@@ -62,6 +63,18 @@ def main():
         feeds.append((u, obs, idx.copy(), loc.copy()))
     eng = e._e
     from ekf_slam_amd import _lib as L
+    # Device conditioning, outside the timed region (as bench.py does): the first sustained burst of launches in a process sees a one-off
+    # 35-70 ms stall (scripts/probe_queue.py) -- several times this benchmark's whole timed region.  Burn it on a throw-away engine of
+    # the same configuration that replays the first scans from the same state.
+    if not args.no_conditioning:
+        warm = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=int(eng.cfg.device_assoc))
+        warm.x, warm.s, warm.P = e.x, e.s, e.P
+        for rep in range(3):
+            for u, obs, idx, loc in feeds[:64]:
+                warm._e.predict(u)
+                warm._e.measure(obs, u, idx, loc)
+        warm._e.sync()
+        warm._e.close()
     if args.kernel_timing:
         eng.timing_enable(L.EKF_KERNEL_ASSOCIATE, True, launches=args.steps * args.m + 8)
         eng.timing_enable(L.EKF_KERNEL_GATHER, True, launches=args.steps * args.m + 8)

@@ -260,6 +260,20 @@ K12_P_AFTER2 = np.array([
     [0, .09, 0, 0, .065, 0, 0, 0, .49]])
 
 
+# KAT-13  association costs at heading 90, Correspondence.m:49-87: KAT-7's scene turned by 90 deg about the robot.  Range and RELATIVE
+#     bearing do not change under that rotation, so costs and decisions must be KAT-7's -- but only if z_k = wrapTo360(atan2d(dy,dx) -
+#     x(3)) (:56) is evaluated as written: with + x(3), or atan2d's arguments swapped, landmark 1's predicted bearing is 180 or 270, not 0.
+#     x = [0 0 90 | 0 2 | -4 0],  P = diag(.1 .1 .1 .5 .5 .3 .3), s = [5 5], R = diag(.025, 50)
+#     landmark 1 (0,2):   delta = [0;2],  q = 4,  z_k = [2; wrapTo360(atan2d(2,0) - 90)] = [2; 0]
+#                         H_s = [0 -1 0 0 1; .5 0 -1 -.5 0]  (KAT-11),  phi = diag(.1+.5, .025+.1+.125) + R = diag(.625, 50.25)
+#     landmark 2 (-4,0):  delta = [-4;0], q = 16, z_k = [4; wrapTo360(atan2d(0,-4) - 90)] = [4; wrapTo360(180 - 90)] = [4; 90]
+#                         H_s = (1/16)[16 0 0 -16 0; 0 4 -16 0 -4] = [1 0 0 -1 0; 0 .25 -1 0 -.25]
+#                         phi = diag(.1+.3, .00625+.1+.01875) + R = diag(.425, 50.125)
+#     z = [2.5 10 5]:  nu = [.5; 10], [-1.5; -80]  -> pc = [.4 + 400/201, 90/17 + 51200/401]  = K7_PC_A
+#     z = [4.2 85 5]:  nu = [2.2; 85], [.2; -5]    -> pc = [7.744 + 28900/201, 8/85 + 200/401] = K7_PC_B
+K13_X = np.array([0.0, 0, 90, 0, 2, -4, 0])
+
+
 class KatTable:
     """A landmark_list with a fixed struct array (RANSAC.m:238-241) and a scripted getLandmark: the duck type
     EKF_SLAM*.measure consumes (EKF_SLAM.m:102,111,120)."""

@@ -175,3 +175,17 @@ def test_kat12_uc_measure_with_a_new_landmark_on_the_gpu(device_assoc, tile, bat
     with pytest.raises(EkfError) as ei:
         h.measure(None, K.K12_U, K.KatTable(K.K12_TABLE[:3], K.K12_OBSERVED))
     assert ei.value.status == EKF_ERR_LOOKUP
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_kat13_association_costs_at_heading_90_on_the_gpu(batch):
+    """KAT-7's scene turned by 90 degrees (tests/kat_cases.py): k_associate's z_k = wrapTo360(atan2d(dy,dx) - x(3)), Correspondence.m:56."""
+    from ekf_slam_amd import Engine
+    for w_pos, thresh, z, want in [(0.0, 1e9, K.K7_ZA, (False, 1)), (1.0, 1e9, K.K7_ZA, (False, 1)), (1.0, 1e9, K.K7_ZB, (False, 2)),
+                                   (1.0, 2.0, K.K7_ZA, (True, 3))]:
+        e = Engine(mode="uc", capacity=4, tile=16, batch=batch, s_cost=1.0, s_thresh=thresh, w_pos=w_pos)
+        e.set_state(K.K13_X, K.K7_P, K.K7_S)
+        new, idx0, pc, sc = e.associate(z, K.K7_R, want_costs=True)
+        assert (new, idx0 + 1) == want, (w_pos, thresh, z)
+        np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
+        e.close()

@@ -239,6 +239,21 @@ def test_kat12_uc_measure_with_a_new_landmark_by_hand(oracle_lib):
         d.measure(None, K.K12_U, K.KatTable(K.K12_TABLE[:3], K.K12_OBSERVED))
 
 
+def test_kat13_association_costs_at_heading_90_by_hand(oracle_lib):
+    """Correspondence.m:49-87 (KAT-13): KAT-7's scene turned by 90 degrees about the robot -- same ranges, same relative bearings, so
+    the same Mahalanobis costs and decisions, provided z_k = wrapTo360(atan2d(dy,dx) - x(3)) is evaluated as written (:56)."""
+    c = D.Correspondence(1.0, 1e9, 'EKF_SLAM_UC')
+    for z, pc in ((K.K7_ZA, K.K7_PC_A), (K.K7_ZB, K.K7_PC_B)):
+        assert c.estimateCorrespondence(z, K.K7_R, K.K13_X, K.K7_P, K.K7_S) == (False, 1)
+        np.testing.assert_allclose(c.last_position_cost, pc, rtol=1e-14)
+    for w_pos, thresh, z, want in [(1.0, 1e9, K.K7_ZA, (False, 1)), (1.0, 1e9, K.K7_ZB, (False, 2)), (1.0, 2.0, K.K7_ZA, (True, 3))]:
+        st = StructuredEKF(4, "uc", s_cost=1.0, s_thresh=thresh, w_pos=w_pos)
+        st.set_state(K.K13_X, K.K7_P, K.K7_S)
+        new, idx, pc, sc = st.associate(z, K.K7_R, want_costs=True)
+        assert (new, idx) == want, (w_pos, thresh, z)
+        np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
+
+
 @pytest.mark.parametrize("mode", ["known", "uc"])
 def test_dense_equals_structured_20_landmarks(mode, oracle_lib):
     _, run = make_run(20, 20260101, 60, policy="all")
