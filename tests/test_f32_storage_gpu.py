@@ -56,3 +56,26 @@ def test_f32_halves_the_tile_store():
     a = Engine(capacity=2000, storage="f64", tile=128).device_bytes()
     b = Engine(capacity=2000, storage="f32", tile=128).device_bytes()
     assert b < 0.56 * a
+
+
+@pytest.mark.parametrize("tile,batch", [(16, 1), (256, 4), (128, 8)])
+def test_f32_tiles_unknown_correspondence_device_loop_equals_host_decided(tile, batch, oracle_lib):
+    """EKF_SLAM_UC.measure on F32 tiles: the device-resident loop (cfg.device_assoc = 3: the association evaluated in the gather
+    kernel's epilogue from float tiles + f64 pending pairs) against the host-decided mode -- same decisions, so the same F32
+    state bit for bit -- and against the F64 oracle at the short-run F32 tolerance."""
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle.ekf_structured import StructuredEKF
+    _, run = make_run(40, 5, 10, policy="nearest", m=6)
+    dev = EKF_SLAM_UC(capacity=48, tile=tile, batch=batch, storage="f32")
+    host = EKF_SLAM_UC(capacity=48, tile=tile, batch=batch, storage="f32", device_assoc=0)
+    assert dev._e.cfg.device_assoc == 3
+    ref = StructuredEKF(48, "uc")
+    ld, lh, lr = Landmark('SYNTHETIC'), Landmark('SYNTHETIC'), SyntheticLandmark()
+    for u, scan in run:
+        for e, l in ((dev, ld), (host, lh), (ref, lr)):
+            e.predict(u); e.measure(scan, u, l)
+    assert dev._e.N == host._e.N == ref.N == 40
+    np.testing.assert_array_equal(dev.x, host.x)
+    np.testing.assert_array_equal(dev.P, host.P)
+    assert rel_err(dev.x, ref.x) < TOL_X and rel_err(dev.P, ref.P) < TOL_P
