@@ -32,7 +32,12 @@ classdef ShardedEKF < handle
                 ekfslam_mex('append', g.hnd(r), double(u(:)), double(R), double(landmarkPos(:)), double(signature));
             end
         end
-        function correct(g, z, R, idx)        % correction body of measure() for landmark idx (1-based)
+        function correct(g, z, R, idx, next_idx)   % correction body of measure() for landmark idx (1-based)
+            % next_idx (optional): the landmark the NEXT correct() will name -- this correction's pass over P then also extracts that
+            % landmark's row-panel (ekf_hint_next; result-neutral, saves the next step's extraction launch when batch == 1)
+            if nargin > 4 && ~isempty(next_idx)
+                for r = 1:numel(g.hnd), ekfslam_mex('hint_next', g.hnd(r), next_idx); end
+            end
             for r = 1:numel(g.hnd), ekfslam_mex('correct_begin', g.hnd(r), double(z(:)), double(R), idx); end
             ekfslam_mex('exchange_local', g.hnd);
             for r = 1:numel(g.hnd), ekfslam_mex('correct_finish', g.hnd(r)); end

@@ -120,6 +120,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     /* sharded handles driven by one host thread: begin on every shard, 'exchange_local', finish on every shard */
     if (!strcmp(cmd, "correct_begin")) { need(nrhs, 5, cmd); check(h, ekf_correct_begin(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), (int64_t)mxGetScalar(prhs[4]) - 1)); return; }
     if (!strcmp(cmd, "correct_finish")) { check(h, ekf_correct_finish(h)); return; }
+    if (!strcmp(cmd, "hint_next")) { need(nrhs, 3, cmd); check(h, ekf_hint_next(h, (int64_t)mxGetScalar(prhs[2]) - 1)); return; }   /* idx 1-based */
     if (!strcmp(cmd, "associate_begin")) {        /* (h, z 1x3, R 2x2): candidates of this shard into its send area */
         need(nrhs, 4, cmd);
         check(h, ekf_associate_begin(h, mxGetPr(prhs[2]), mxGetPr(prhs[3]), 0));

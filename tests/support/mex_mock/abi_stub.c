@@ -70,6 +70,7 @@ int32_t ekf_get_Q(ekf_handle *h, double Q[9]) { LOG("ekf_get_Q"); for (int i = 0
 int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx) {
     LOG("ekf_correct_begin rank=%d z=%g,%g R=%g,%g,%g,%g idx0=%lld", h->rank, z[0], z[1], R[0], R[1], R[2], R[3], (long long)idx); return st(h); }
 int32_t ekf_correct_finish(ekf_handle *h) { LOG("ekf_correct_finish rank=%d", h->rank); return st(h); }
+int32_t ekf_hint_next(ekf_handle *h, int64_t idx) { LOG("ekf_hint_next rank=%d idx0=%lld", h->rank, (long long)idx); return st(h); }
 int32_t ekf_associate_begin(ekf_handle *h, const double z[3], const double R[4], int32_t want_costs) {
     LOG("ekf_associate_begin rank=%d z=%g,%g,%g R=%g,%g,%g,%g costs=%d", h->rank, z[0], z[1], z[2], R[0], R[1], R[2], R[3], want_costs); return st(h); }
 int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pc, double *sc) {

@@ -89,6 +89,8 @@ int main(void) {
     mxArray *g1 = out[0];
     const uint64_t hv[2] = { *(uint64_t *)mxGetData(g0), *(uint64_t *)mxGetData(g1) }, hbad[2] = { hv[0], 0 };
     mxArray *gv = mock_uint64_vec(2, hv);
+    call(0, 3, S("hint_next"), g0, D1(7));
+    call(0, 3, S("hint_next"), g1, D1(7));
     call(0, 5, S("correct_begin"), g0, mock_double(2, 1, z2), mock_double(2, 2, R), D1(3));
     call(0, 5, S("correct_begin"), g1, mock_double(2, 1, z2), mock_double(2, 2, R), D1(3));
     call(0, 2, S("exchange_local"), gv);

@@ -113,6 +113,7 @@ def test_gateway_marshalling_under_the_mock(transcript):
     assert [ln.split()[1] for ln in t[i - 4:i + 5] if ln.startswith("ABI ")] == \
         ["ekf_correct_begin", "ekf_correct_begin", "ekf_exchange_local", "ekf_correct_finish", "ekf_correct_finish"]
     assert "ABI ekf_correct_begin rank=1 z=5,50 R=0.05,0,0,250 idx0=2" in t
+    assert "ABI ekf_hint_next rank=1 idx0=6" in t                                  # ekf_hint_next: 1-based -> 0-based once
     assert "ABI ekf_associate_begin rank=0 z=5,50,7 R=0.05,0,0,250 costs=0" in t
     assert any(ln.startswith("MEX associate_finish") and "out0=1x1L[0] out1=1x1[5]" in ln for ln in t)
     assert any(ln.startswith("MEX create nrhs=6 -> ERROR ekfslam:usage") for ln in t)
