@@ -505,6 +505,11 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     return EKF_OK;
 }
 
+// the buffer the PENDING exchange's contribution sits in (what a caller-run all-gather must send)
+double *pending_send(const ekf_handle *h) {
+    return (h->pending && h->pending_kind == 1) ? corr_send(h, h->x_count) : h->send;
+}
+
 constexpr int kThrottle = 48;
 
 // run-ahead throttle (see ekf_handle::throttle_ev): called once per update-step
@@ -605,7 +610,7 @@ int32_t exchange_rccl(ekf_handle *h) {
     REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
             "sharded handle without a communicator: call ekf_comm_init, or drive the begin / your own all-gather / "
             "finish calls");
-    const double *src = h->pending_kind == 1 ? corr_send(h, h->x_count) : h->send;
+    const double *src = pending_send(h);
     const int r = g_rccl.AllGather(src, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
     if (r != 0) { h->pending = false; return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r)); }
     return EKF_OK;
@@ -1383,7 +1388,7 @@ int32_t ekf_prefetch_rows(ekf_handle *h, const int64_t *idx, int32_t m) {
 int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity) {
     if (!h) return EKF_ERR_INVALID_ARG;
     REQUIRE(h, h->sharded, EKF_ERR_STATE, "exchange_info: handle is not sharded");
-    if (send) *send = h->send;
+    if (send) *send = pending_send(h);
     if (recv) *recv = h->recv;
     if (count) *count = h->pending ? h->x_count : h->slab;
     if (count_capacity) *count_capacity = h->xchg_cap;
@@ -1415,9 +1420,12 @@ int32_t ekf_exchange_local(ekf_handle **hs, int32_t world) {
     for (int dst = 0; dst < world; ++dst) {
         ekf_handle *d = hs[dst];
         HIPCHK(d, hipSetDevice(d->cfg.device));
-        for (int src = 0; src < world; ++src)
-            HIPCHK(d, hipMemcpyPeerAsync(d->recv + (size_t)src * d->x_count, d->cfg.device, hs[src]->send,
-                                         hs[src]->cfg.device, bytes, d->stream));
+        for (int src = 0; src < world; ++src) {
+            const double *from = pending_send(hs[src]);
+            double *to = d->recv + (size_t)src * d->x_count;
+            if (from == to) continue;                                  // already in place (own segment of the own receive area)
+            HIPCHK(d, hipMemcpyPeerAsync(to, d->cfg.device, from, hs[src]->cfg.device, bytes, d->stream));
+        }
         if (!d->ev_xchg) HIPCHK(d, hipEventCreateWithFlags(&d->ev_xchg, hipEventDisableTiming));
         HIPCHK(d, hipEventRecord(d->ev_xchg, d->stream));
     }
