@@ -54,3 +54,26 @@ def test_one_thousand_landmarks_unknown_correspondence(oracle_lib):
     new_r, idx_r, pc_r, sc_r = ref.associate(z, R, want_costs=True)
     assert (new_g, idx_g + 1) == (new_r, idx_r)
     assert rel_err(pc_g, pc_r) < REL and rel_err(sc_g, sc_r) < REL
+
+
+@pytest.mark.parametrize("batch,asy", [(24, False), (40, False), (32, True)])
+def test_device_loop_with_many_pending_pairs(batch, asy, oracle_lib):
+    """The device-resident loop's gather kernel keeps the operands of the first 16 pending pairs in registers (both operands: its
+    epilogue needs K_i(c,:) AND G_i(:,c)) and fetches the rest in chunks; batches of 24 / 40 and an asynchronous flush (up to 2 x 32
+    pairs pending) walk every one of those paths -- against the host-decided mode bit for bit, and the oracle to 1e-6."""
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle.ekf_structured import StructuredEKF
+    n_lm = 300
+    _, run = make_run(n_lm, 20260111, 2 + 45, policy="nearest", m=8)
+    dev = EKF_SLAM_UC(capacity=n_lm, batch=batch, async_flush=asy)
+    host = EKF_SLAM_UC(capacity=n_lm, batch=batch, async_flush=asy, device_assoc=0)
+    ref = StructuredEKF(n_lm, "uc")
+    ld, lh, lr = Landmark('SYNTHETIC'), Landmark('SYNTHETIC'), SyntheticLandmark()
+    for u, scan in run:
+        for e, l in ((dev, ld), (host, lh), (ref, lr)):
+            e.predict(u); e.measure(scan, u, l)
+    assert dev._e.N == host._e.N == ref.N == n_lm
+    np.testing.assert_array_equal(dev.x, host.x)
+    np.testing.assert_array_equal(dev.P, host.P)
+    assert rel_err(dev.x, ref.x) < REL and rel_err(dev.P, ref.P) < REL
