@@ -274,6 +274,29 @@ K12_P_AFTER2 = np.array([
 K13_X = np.array([0.0, 0, 90, 0, 2, -4, 0])
 
 
+# KAT-14  measure() with KNOWN correspondence, the two dispatch quirks of EKF_SLAM.m:116-123
+#   (a) :123  idx = ii -- the ROW NUMBER, not z(3).  x = [0 0 0 | 2 0 | 0 4], P = diag(.1 .1 .1 .5 .5 .3 .3), one observed row [2.5 10 2]:
+#       z(3) = 2 <= N = 2 -> correction with idx = ii = 1: landmark ONE is corrected with an observation that names landmark two.
+#       R = diag(2.5*.01, 10*5) = diag(.025, 50) (Rc = [.01 5], :13,:108) -> exactly KAT-5 on the first five states; landmark 2 (no
+#       cross-covariance with anything) keeps (0, 4) and .3 I.
+#   (b) :118-120  z(3) > N -> append(u, R, loc of the table entry whose index == z(3), z(3)): the stored signature is z(3) itself (5 here,
+#       not N+1 = 3 as in the UC class).  State = KAT-12 after its first row (heading 90), u = [2 90], row [4 30 5], R = diag(.04, 150):
+#       jxr = [1 0 -2; 0 1 0], jz = [0 -2; 1 0];  jz R jz' = [0 -300; .04 0][0 1; -2 0] = diag(600, .04);  C = diag(.25+600, .09+.04)
+#       everything else as KAT-12's append (K12_P_AFTER2) -- only P(9,9) = .13 instead of .49.
+K14A_X = K7_X
+K14A_P = K7_P
+K14A_OBSERVED = np.array([[2.5, 10.0, 2.0]])
+K14A_X_OUT = np.concatenate([K5_X_OUT, [0.0, 4.0]])
+K14A_P_OUT = np.zeros((7, 7)); K14A_P_OUT[:5, :5] = K5_P_OUT; K14A_P_OUT[5, 5] = K14A_P_OUT[6, 6] = .3
+K14B_X = K12_X_AFTER2[:7]
+K14B_P = K12_P_AFTER2[:7, :7]
+K14B_TABLE = [(1, (0.0, 2.0)), (2, (0.0, -2.55)), (3, (9.0, 9.0)), (5, (-1.0, 6.0))]
+K14B_OBSERVED = np.array([[4.0, 30.0, 5.0]])
+K14B_X_OUT = K12_X_AFTER2
+K14B_P_OUT = K12_P_AFTER2.copy(); K14B_P_OUT[8, 8] = .13
+K14B_S_OUT = np.array([1.0, 2.0, 5.0])
+
+
 class KatTable:
     """A landmark_list with a fixed struct array (RANSAC.m:238-241) and a scripted getLandmark: the duck type
     EKF_SLAM*.measure consumes (EKF_SLAM.m:102,111,120)."""

@@ -189,3 +189,20 @@ def test_kat13_association_costs_at_heading_90_on_the_gpu(batch):
         assert (new, idx0 + 1) == want, (w_pos, thresh, z)
         np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
         e.close()
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+def test_kat14_known_correspondence_dispatch_quirks_on_the_gpu(tile, batch):
+    """EKF_SLAM.measure through the reference-named class: idx = ii (EKF_SLAM.m:123) and the z(3) > N append (:118-120)."""
+    from ekf_slam_amd.slam import EKF_SLAM
+    h = EKF_SLAM(capacity=4, tile=tile, batch=batch)
+    h.x, h.s, h.P = K.K14A_X, [1.0, 2.0], K.K14A_P
+    h.measure(None, [0.1, 0.0], K.KatTable(K.K12_TABLE, K.K14A_OBSERVED))
+    np.testing.assert_allclose(h.x, K.K14A_X_OUT, rtol=0, atol=2e-16)
+    np.testing.assert_allclose(h.P, K.K14A_P_OUT, rtol=0, atol=2e-16)
+    h = EKF_SLAM(capacity=4, tile=tile, batch=batch)
+    h.x, h.s, h.P = K.K14B_X, [1.0, 2.0], K.K14B_P
+    h.measure(None, K.K12_U, K.KatTable(K.K14B_TABLE, K.K14B_OBSERVED))
+    np.testing.assert_allclose(h.x, K.K14B_X_OUT, rtol=0, atol=5e-16)
+    np.testing.assert_allclose(h.P, K.K14B_P_OUT, rtol=0, atol=2e-13)
+    np.testing.assert_array_equal(h.s, K.K14B_S_OUT)

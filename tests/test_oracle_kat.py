@@ -254,6 +254,22 @@ def test_kat13_association_costs_at_heading_90_by_hand(oracle_lib):
         np.testing.assert_allclose(pc, K.K7_PC_A if z[0] == 2.5 else K.K7_PC_B, rtol=1e-14)
 
 
+def test_kat14_known_correspondence_dispatch_quirks_by_hand(oracle_lib):
+    """EKF_SLAM.m:116-123 (KAT-14): idx = ii corrects the landmark of the ROW NUMBER whatever z(3) says; z(3) > N appends with
+    signature z(3) and the loc of the table entry whose index is z(3)."""
+    for name, e, _ in _both("known", 8):
+        _load(e, K.K14A_X, K.K14A_P, [1.0, 2.0])
+        e.measure(None, [0.1, 0.0], K.KatTable(K.K12_TABLE, K.K14A_OBSERVED))
+        np.testing.assert_allclose(e.x, K.K14A_X_OUT, rtol=0, atol=2e-16, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K14A_P_OUT, rtol=0, atol=2e-16, err_msg=name)
+    for name, e, _ in _both("known", 8):
+        _load(e, K.K14B_X, K.K14B_P, [1.0, 2.0])
+        e.measure(None, K.K12_U, K.KatTable(K.K14B_TABLE, K.K14B_OBSERVED))
+        np.testing.assert_allclose(e.x, K.K14B_X_OUT, rtol=0, atol=5e-16, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K14B_P_OUT, rtol=0, atol=2e-13, err_msg=name)
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), K.K14B_S_OUT)
+
+
 @pytest.mark.parametrize("mode", ["known", "uc"])
 def test_dense_equals_structured_20_landmarks(mode, oracle_lib):
     _, run = make_run(20, 20260101, 60, policy="all")
