@@ -86,6 +86,11 @@ struct ekf_handle {
     bool have_pp = false;
     PredictArgs pp;
     std::vector<double> s_host;   // host mirror of the signatures (they only change through host calls)
+    // (signature, landmark) sorted by signature: the signature-only decision of a large map looks at the few landmarks whose
+    // signature lies within the threshold of z(3) instead of all N (the mirror's O(N) scan per observation would pace the host
+    // at ~10 us per row from 10 k landmarks on).  Rebuilt lazily after bulk changes, kept up to date by appends.
+    mutable std::vector<std::pair<double, int64_t>> s_sorted;
+    mutable bool s_sorted_ok = false;
     // run-ahead throttle: the host may queue at most ~2*kThrottle update-steps ahead of the device.  Measured: the
     // first time ~150-190 launches are outstanding on a stream, one launch call blocks for 35-45 ms (the runtime
     // grows a per-queue pool); with the run-ahead bounded below that the stall never happens.
@@ -497,8 +502,12 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
         TimedLaunch tl(h, EKF_KERNEL_APPEND);
         HIPCHK(h, launch_append(h->st, a, h->storage, h->stream, dl));
     }
-    if ((int64_t)h->s_host.size() > h->N) h->s_host.resize((size_t)h->N);
+    if ((int64_t)h->s_host.size() > h->N) { h->s_host.resize((size_t)h->N); h->s_sorted_ok = false; }
     h->s_host.push_back(signature);
+    if (h->s_sorted_ok && signature == signature) {       // keep the index sorted by (signature, landmark); NaN never matches anything
+        const std::pair<double, int64_t> e(signature, h->N);
+        h->s_sorted.insert(std::upper_bound(h->s_sorted.begin(), h->s_sorted.end(), e), e);
+    }
     h->N += 1;
     h->pf_valid = false;
     h->nx_valid = false;
@@ -849,16 +858,39 @@ int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_
     return collect_decision(h, set, assoc_blocks(N), seq, N, !pos_cost && !sig_cost, is_new, idx);
 }
 
-// Correspondence.m:40-43,71,75,78-85 with the live likelihood (signature cost only)
+// Correspondence.m:40-43,71,75,78-85 with the live likelihood (signature cost only): the landmark of lowest likelihood among those
+// at or below the threshold, the lowest index on ties (strict '<' in index order, :81); nothing below the threshold -> (new, N).
 void associate_signature_only(const ekf_handle *h, double z3, int32_t *is_new, int64_t *idx) {
     const int64_t N = h->N;
     *is_new = 1; *idx = N;
     double best = INFINITY;
-    const double inv_cost = 1.0 / h->cfg.s_cost;
+    const double inv_cost = 1.0 / h->cfg.s_cost, thresh = h->cfg.s_thresh;
+    // ll = (d c) d <= thresh only if |d| <= sqrt(thresh / c) (up to rounding: the window below is a strict superset); on a
+    // large map only the landmarks inside that window of the sorted index are evaluated -- with the very same expression
+    const double w = (inv_cost > 0.0 && thresh >= 0.0) ? sqrt(thresh / inv_cost) * (1.0 + 1e-9) + 1e-300 : INFINITY;
+    if (N >= 256 && w < INFINITY && z3 == z3) {
+        if (!h->s_sorted_ok || (int64_t)h->s_sorted.size() > N) {
+            h->s_sorted.clear();
+            h->s_sorted.reserve((size_t)N);
+            for (int64_t k = 0; k < N; ++k) if (h->s_host[(size_t)k] == h->s_host[(size_t)k]) h->s_sorted.emplace_back(h->s_host[(size_t)k], k);
+            std::sort(h->s_sorted.begin(), h->s_sorted.end());
+            h->s_sorted_ok = true;
+        }
+        const auto lo = std::lower_bound(h->s_sorted.begin(), h->s_sorted.end(), std::pair<double, int64_t>(z3 - w, -1));
+        const auto hi = std::upper_bound(lo, h->s_sorted.end(), std::pair<double, int64_t>(z3 + w, INT64_MAX));
+        if (hi - lo < N / 2) {
+            for (auto it = lo; it != hi; ++it) {
+                const double d = z3 - it->first;
+                const double ll = d * inv_cost * d;
+                if (ll <= thresh && (ll < best || (ll == best && it->second < *idx))) { *is_new = 0; best = ll; *idx = it->second; }
+            }
+            return;
+        }
+    }
     for (int64_t k = 0; k < N; ++k) {
         const double d = z3 - h->s_host[(size_t)k];
         const double ll = d * inv_cost * d;
-        if (ll <= h->cfg.s_thresh && ll < best) { *is_new = 0; best = ll; *idx = k; }
+        if (ll <= thresh && ll < best) { *is_new = 0; best = ll; *idx = k; }
     }
 }
 
@@ -1509,6 +1541,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     h->pf_valid = false;       // a prefetch belongs to the state it was taken from
     h->nx_valid = false;
     h->s_host.resize((size_t)h->N, 0.0);
+    h->s_sorted_ok = false;
     HIPCHK(h, hipMemcpyAsync(h->st.x[h->cur], x, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return EKF_OK;
@@ -1531,6 +1564,7 @@ int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
     if (N > 0) HIPCHK(h, hipMemcpyAsync(h->st.s, s, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->s_host.assign(s, s + N);
+    h->s_sorted_ok = false;
     return EKF_OK;
 }
 
@@ -1629,6 +1663,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     }
     h->N = N;
     h->s_host.assign(s, s + N);
+    h->s_sorted_ok = false;
     { const int32_t rcr = retire_inflight(h); if (rcr) return rcr; }
     h->npend = 0; h->pstart = 0;   // the whole state is replaced ...
     h->pf_valid = false;           // ... and with it every prefetched base row-panel
@@ -1760,6 +1795,7 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     // N follows x even when a later section failed (an I/O error mid-way): x and N must never disagree
     h->N = hd.N;
     h->s_host = shost;
+    h->s_sorted_ok = false;
     h->work_rows = -1;
     return done(rc);
 }

@@ -127,3 +127,44 @@ def test_capacity_reached_exactly_then_refused():
     assert ei.value.status == L.EKF_ERR_CAPACITY and e.N == 3
     e.correct([2.0, 40.0], R, 2); d._correct([2.0, 40.0], R, 3)            # still usable at capacity
     assert rel_err(e.get_x(), d.x) < REL and rel_err(e.get_P(), d.P) < REL
+
+
+@pytest.mark.parametrize("device_assoc", [2, 3])
+def test_signature_index_of_the_host_mirror_agrees_with_the_device_on_ties_and_threshold_edges(device_assoc):
+    """From 256 landmarks on, the host's prediction of an observation's association (the mirror of s) evaluates only the landmarks
+    whose signature lies within the threshold of z(3), found in a sorted index; the device evaluates all N.  Duplicate signatures
+    (the lowest index must win, Correspondence.m:81), signatures exactly on / just beyond the threshold, observations matching
+    nothing (appended, which also extends the index): every device decision is checked against the host's (modes 2 and 3 verify)."""
+    from ekf_slam_amd import Engine
+    rng = np.random.default_rng(123)
+    N = 400
+    n = 3 + 2 * N
+    x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-30, 30, size=2 * N)])
+    U = rng.normal(0, 0.05, size=(n, 4))
+    P = np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T
+    s = rng.integers(1, 60, size=N).astype(float) + rng.choice([0.0, 0.05, 0.1, -0.05], size=N)       # many duplicates and near-duplicates
+    e = Engine(mode="uc", capacity=N + 40, tile=64, batch=4, device_assoc=device_assoc, s_cost=1.0, s_thresh=0.01)   # |d| <= 0.1 passes
+    ref = Engine(mode="uc", capacity=N + 40, tile=64, batch=4, device_assoc=1, s_cost=1.0, s_thresh=0.01)           # waited: the device decides
+    for g in (e, ref):
+        g.set_state(x, P, s)
+    u = [0.1, 2.0]
+    appended = 0
+    for scan in range(12):
+        rows = []
+        for _ in range(6):
+            base = float(rng.integers(0, 62))
+            z3 = base + float(rng.choice([0.0, 0.05, 0.1, 0.1000001, -0.1, -0.0999999, 0.15, 0.5]))
+            rows.append([float(rng.uniform(2, 30)), float(rng.uniform(1, 359)), z3])
+        Ncur = e.N
+        idx = np.arange(Ncur + 1, Ncur + 8, dtype=float)                      # table entries for every index an append may ask for
+        loc = rng.uniform(-30, 30, (7, 2))
+        for g in (e, ref):
+            g.predict(u)
+            g.measure(rows, u, idx, loc)
+        e.sync()                                                              # mode 3 reports a mismatch here at the latest
+        appended += e.N - Ncur
+        assert e.N == ref.N
+    assert appended > 0 and e.N > N
+    np.testing.assert_array_equal(e.get_s(), ref.get_s())
+    np.testing.assert_array_equal(e.get_x(), ref.get_x())
+    np.testing.assert_array_equal(e.get_P(), ref.get_P())
