@@ -66,6 +66,7 @@ struct ekf_handle {
     int32_t T = 64;
     int32_t storage = 0;
     int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
+    uint32_t pass_seq = 0; // passes over P so far: seeds the stochastic rounding of F32 tile stores (kernels.hip::round_tile); saved in checkpoints
     int32_t batch = 1;     // corrections per pass over P
     int32_t npend = 0;     // pending pairs a reader must apply (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
     int32_t pstart = 0;    // ring slot of the oldest pending pair
@@ -322,6 +323,9 @@ void next_pass_direction(ekf_handle *h) {
     const int64_t store = nt * (nt + 1) / 2 / std::max(1, h->cfg.world) * (int64_t)h->T * h->T * (h->storage == EKF_STORE_F64 ? 8 : 4);
     const bool alternate = force >= 0 ? force != 0 : store > kCacheBytes;
     h->st.tm.reverse = alternate ? (h->st.tm.reverse ^ 1) : 0;
+    // ... and every pass has a number: F32 tiles round what they store stochastically, seeded by (element, pass) -- kernels.hip::round_tile
+    if (++h->pass_seq == 0u) h->pass_seq = 1u;                        // 0 means "round to nearest"
+    h->st.tm.pass = h->cfg.f32_rounding == 1 ? 0u : h->pass_seq;
 }
 
 int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
@@ -659,6 +663,10 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     static const bool fuse_small = ekf_tune_int("EKF_FUSE_SMALL", 1) != 0;
     const bool fused = fuse_small && h->batch == 1 && !h->async_flush && h->npend == 0 && a.n_mm <= gather_fuse_max_rows() &&
                        ekf_tiles_for(a.n_mm, h->T) * h->T <= 256;
+    if (fused) {                     // this launch is also a pass over P: it gets a number like the others (F32 tile rounding)
+        if (++h->pass_seq == 0u) h->pass_seq = 1u;
+        h->st.tm.pass = h->cfg.f32_rounding == 1 ? 0u : h->pass_seq;
+    }
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
@@ -1691,7 +1699,8 @@ struct CkptHeader {
     int64_t N;
     int32_t tile, storage, world, rank;
     int64_t tile_bytes;      // bytes of the tile section
-    int64_t reserved[3];
+    int64_t pass_seq;        // passes over P so far (seeds the rounding of F32 tile stores: a resumed run continues bit for bit)
+    int64_t reserved[2];
 };
 static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
 
@@ -1737,6 +1746,7 @@ int32_t ekf_checkpoint_save(ekf_handle *h, const char *path) {
     memcpy(hd.magic, "EKFSLAM1", 8);
     hd.N = h->N; hd.tile = h->T; hd.storage = h->storage; hd.world = h->cfg.world; hd.rank = h->cfg.rank;
     hd.tile_bytes = h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h);
+    hd.pass_seq = (int64_t)h->pass_seq;
     rc = fwrite(&hd, sizeof hd, 1, f) == 1 ? EKF_OK : fail(h, EKF_ERR_STATE, "checkpoint: short write");
     if (!rc) rc = stream_out(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
     if (!rc && h->N > 0) rc = stream_out(h, f, h->st.s, (size_t)h->N * 8, stage, stage_bytes);
@@ -1794,6 +1804,7 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     if (!rc && hd.tile_bytes > 0) rc = stream_in(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
     // N follows x even when a later section failed (an I/O error mid-way): x and N must never disagree
     h->N = hd.N;
+    h->pass_seq = (uint32_t)hd.pass_seq;
     h->s_host = shost;
     h->s_sorted_ok = false;
     h->work_rows = -1;

@@ -66,6 +66,31 @@ __device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
     return fma(-k.y, g.y, fma(-k.x, g.x, v));       // v - K(r,1) G(1,c) - K(r,2) G(2,c): two FMAs, fixed order
 }
 
+// What a pass over P stores.  F64 tiles: the value.  F32 tiles: the value rounded to float -- STOCHASTICALLY, with a deterministic
+// seed: hash(global row, global column, number of the pass).  Round-to-nearest loses every update that is smaller than half an ulp
+// of the entry it applies to, pass after pass in the same direction (stagnation): on a streaming-append map the large diagonal blocks
+// of not-yet-re-observed landmarks then drift from the F64 result LINEARLY, 1.6e-9 per update-step (profiles/round3_f32_drift.json).
+// Rounding up with probability (v - lo) / (hi - lo) is unbiased, so the same updates accumulate like a random walk instead.  The
+// seed depends on the ELEMENT and the PASS only: every kernel instance (MFMA or VALU flush, any tile edge), every shard layout and
+// every replay of the same run stores the same bits.  A value that is a float already is stored unchanged whatever the seed
+// (its low 29 mantissa bits are zero), so entries a pass does not change stay as they are.
+template <typename TS> __device__ __forceinline__ TS round_tile(double v, uint32_t row, uint32_t col, uint32_t pass);
+template <> __device__ __forceinline__ double round_tile<double>(double v, uint32_t, uint32_t, uint32_t) { return v; }
+template <> __device__ __forceinline__ float round_tile<float>(double v, uint32_t row, uint32_t col, uint32_t pass) {
+    // No early return: a branch here splits the caller's 16-byte tile store into scalar stores (3x slower pass).
+    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v);
+    const uint32_t ex0 = (uint32_t)(b0 >> 52) & 0x7ffu;
+    uint32_t h = row * 0x9E3779B1u ^ (col + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (pass + 0x165667B1u) * 0xC2B2AE35u;    // a full avalanche per element:
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;                                                                 // (a cheaper per-group seed measured no faster)
+    unsigned long long b = b0 + (unsigned long long)(h & 0x1fffffffu);      // 29 = 52 - 23 dropped mantissa bits: carry into the kept ones
+    b &= ~0x1fffffffull;                                                     //   with probability (dropped part) / 2^29, then truncate
+    // round to nearest instead (the conversion below does it on the untouched bits) where asked for (pass 0) and for Inf / NaN;
+    // selects only -- a branch per element (even a wave-uniform, never-taken one) cost the 12-pair flush 0.6 ms of 5
+    b = EKF_SEL((pass == 0u) | (ex0 == 0x7ffu)) ? b0 : b;
+    return (float)__longlong_as_double((long long)b);     // exact for the truncated value (+-Inf past FLT_MAX, as rounding up would give;
+                                                          // below float's normal range the conversion rounds what is left -- zero stays zero)
+}
+
 __device__ __forceinline__ int ring_slot(int pstart, int i, int pcap) { const int s = pstart + i; return s >= pcap ? s - pcap : s; }
 
 // live value of canonical element (r >= c enforced here) = base - sum over pending pairs, in slot order
@@ -1167,7 +1192,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             }
 #pragma unroll
             for (int q = 0; q < kFuseElems; ++q)
-                if (ptr[q]) *ptr[q] = (TS)rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]);
+                if (ptr[q]) *ptr[q] = round_tile<TS>(rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]), rr[q], cq[q], st.tm.pass);
         }
     }
     if constexpr (kDev) {
@@ -1304,7 +1329,8 @@ __global__ __launch_bounds__(kBlock) void k_downdate(const TS *__restrict__ tile
             const int r = r0 + p * kRowsPerPass;
             if (kExact || r < kSlab) {
                 V2 o;
-                o.x = (TS)v[p].x; o.y = (TS)v[p].y;
+                const uint32_t grow = (uint32_t)(ij.x * T + slab * kSlab + r), gcl = (uint32_t)(ij.y * T + 2 * cp);
+                o.x = round_tile<TS>(v[p].x, grow, gcl, tm.pass); o.y = round_tile<TS>(v[p].y, grow, gcl + 1u, tm.pass);
                 *reinterpret_cast<V2 *>(td + r * T + 2 * cp) = o;
             }
         }
@@ -1322,10 +1348,13 @@ template <> struct Lane16<double> { using type = double2; static constexpr int k
 template <> struct Lane16<float>  { using type = float4;  static constexpr int kCols = 4; };
 __device__ __forceinline__ void lane16_unpack(const double2 &t, double *v) { v[0] = t.x; v[1] = t.y; }
 __device__ __forceinline__ void lane16_unpack(const float4 &t, double *v) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-__device__ __forceinline__ void lane16_pack(const double *v, double2 &t) { t.x = v[0]; t.y = v[1]; }
-__device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
-    t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
+__device__ __forceinline__ void lane16_pack(const double *v, double2 &t, uint32_t, uint32_t, uint32_t) { t.x = v[0]; t.y = v[1]; }
+__device__ __forceinline__ void lane16_pack(const double *v, float4 &t, uint32_t row, uint32_t col, uint32_t pass) {
+    t.x = round_tile<float>(v[0], row, col, pass); t.y = round_tile<float>(v[1], row, col + 1u, pass);
+    t.z = round_tile<float>(v[2], row, col + 2u, pass); t.w = round_tile<float>(v[3], row, col + 3u, pass);
 }
+__device__ __forceinline__ double lane16_get(const double2 &t, int q) { return q == 0 ? t.x : t.y; }
+__device__ __forceinline__ double lane16_get(const float4 &t, int q) { return (double)(q == 0 ? t.x : q == 1 ? t.y : q == 2 ? t.z : t.w); }
 
 // Out of line on purpose: the pass is HBM-bound to the last per cent, and with this code inlined its main body was scheduled 8 %
 // slower (551 vs 510 us at 10 k landmarks) although only two tile lines in ~150 ever come here.
@@ -1429,11 +1458,11 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
                 for (int q = 0; q < kCols; ++q) v[p][q] = rank2_apply(v[p][q], k, g[q]);
             }
         }
+        VL stored[kPasses];
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
-            VL o;
-            lane16_pack(v[p], o);
-            *reinterpret_cast<VL *>(td + (int64_t)p * kRowsPerInstr * T) = o;
+            lane16_pack(v[p], stored[p], (uint32_t)(ij.x * T + row0 + sub + p * kRowsPerInstr), (uint32_t)(ij.y * T + kCols * cl), tm.pass);
+            *reinterpret_cast<VL *>(td + (int64_t)p * kRowsPerInstr * T) = stored[p];
         }
         if constexpr (kNext) {
             const int Ij = (int)(nx.j >> tm.shift);
@@ -1442,7 +1471,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
                 for (int p = 0; p < kPasses; ++p) {
                     double vv[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-                    for (int q = 0; q < kCols; ++q) vv[q] = (double)(TS)v[p][q];   // what the tile now holds
+                    for (int q = 0; q < kCols; ++q) vv[q] = lane16_get(stored[p], q);      // what the tile now holds
                     extract_next_row(nx.send, (int)(nx.j & (T - 1)), Ij, ij.x, ij.y, row0 + sub + p * kRowsPerInstr, kCols * cl, kCols, T,
                                      tm.world, tm.rank, vv[0], vv[1], vv[2], vv[3]);
                 }
@@ -2043,13 +2072,30 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
                     }
             }
         }
+        typedef TS store16_t __attribute__((ext_vector_type(kE)));                  // the lane's 16 bytes of a row: ONE store instruction
+        if (sizeof(TS) == 8 || tm.pass == 0u) {                                     // (uniform) plain stores: F64 tiles, or F32 rounded to nearest
 #pragma unroll
-        for (int bp = 0; bp < kBP; ++bp)
+            for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r) {
+                    store16_t o;
 #pragma unroll
-                for (int e = 0; e < kE; ++e)
-                    __builtin_nontemporal_store((TS)acc[bp][e][r], td + (int64_t)(4 * r) * T + 16 * kE * bp + e);
+                    for (int e = 0; e < kE; ++e) o[e] = (TS)acc[bp][e][r];
+                    __builtin_nontemporal_store(o, reinterpret_cast<store16_t *>(td + (int64_t)(4 * r) * T + 16 * kE * bp));
+                }
+        } else {
+#pragma unroll
+            for (int bp = 0; bp < kBP; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    store16_t o;
+#pragma unroll
+                    for (int e = 0; e < kE; ++e)
+                        o[e] = round_tile<TS>(acc[bp][e][r], (uint32_t)(ij.x * T + row0 + lr + 4 * r),
+                                              (uint32_t)(ij.y * T + cpart * kCols + 16 * kE * bp + kE * lc + e), tm.pass);
+                    __builtin_nontemporal_store(o, reinterpret_cast<store16_t *>(td + (int64_t)(4 * r) * T + 16 * kE * bp));
+                }
+        }
     }
 }
 
