@@ -37,7 +37,10 @@ class Engine:
         cfg.async_flush = 1 if async_flush else 0
         if device_assoc is not None:              # None: the mode's default (uc: 3, the device-resident loop); include/ekfslam.h
             cfg.device_assoc = int(device_assoc)  # 0: host mirror, 1: device, waited for, 2: device, verified before measure() returns
+        fields = {f[0] for f in L.EkfConfig._fields_}
         for k, v in overrides.items():
+            if k not in fields:                   # (setattr on a ctypes struct would silently create a Python attribute)
+                raise TypeError("Engine: unknown ekf_config field %r" % k)
             if k == "Rc":
                 cfg.Rc[0], cfg.Rc[1] = float(v[0]), float(v[1])
             else:
