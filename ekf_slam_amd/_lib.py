@@ -31,7 +31,7 @@ class EkfConfig(ctypes.Structure):
     _fields_ = [("C", _d), ("Rc", _d * 2), ("s_cost", _d), ("s_thresh", _d), ("w_pos", _d),
                 ("capacity_landmarks", _i64), ("mode", _i32), ("storage", _i32), ("device", _i32),
                 ("tile", _i32), ("rank", _i32), ("world", _i32), ("batch", _i32), ("async_flush", _i32), ("device_assoc", _i32),
-                ("pass_direction", _i32), ("force_sharded", _i32), ("f32_rounding", _i32), ("reserved", _i32 * 2)]
+                ("pass_direction", _i32), ("force_sharded", _i32), ("reserved", _i32 * 3)]
 
 
 # name -> (restype, argtypes); every symbol of include/ekfslam.h

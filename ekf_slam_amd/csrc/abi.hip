@@ -66,7 +66,6 @@ struct ekf_handle {
     int32_t T = 64;
     int32_t storage = 0;
     int32_t cur = 0;       // which of the double buffers holds the live x / Prr / strip
-    uint32_t pass_seq = 0; // passes over P so far: seeds the stochastic rounding of F32 tile stores (kernels.hip::round_tile); saved in checkpoints
     int32_t batch = 1;     // corrections per pass over P
     int32_t npend = 0;     // pending pairs a reader must apply (tiles hold P_base; live P = P_base - sum of pending K_i G_i)
     int32_t pstart = 0;    // ring slot of the oldest pending pair
@@ -323,9 +322,6 @@ void next_pass_direction(ekf_handle *h) {
     const int64_t store = nt * (nt + 1) / 2 / std::max(1, h->cfg.world) * (int64_t)h->T * h->T * (h->storage == EKF_STORE_F64 ? 8 : 4);
     const bool alternate = force >= 0 ? force != 0 : store > kCacheBytes;
     h->st.tm.reverse = alternate ? (h->st.tm.reverse ^ 1) : 0;
-    // ... and every pass has a number: F32 tiles round what they store stochastically, seeded by (element, pass) -- kernels.hip::round_tile
-    if (++h->pass_seq == 0u) h->pass_seq = 1u;                        // 0 means "round to nearest"
-    h->st.tm.pass = h->cfg.f32_rounding == 1 ? 0u : h->pass_seq;
 }
 
 int64_t slab_for(const ekf_handle *h, int64_t mm_rows) {
@@ -541,6 +537,7 @@ int32_t throttle_step(ekf_handle *h) {
 
 int32_t finish_step(ekf_handle *h) {
     h->cur ^= 1;
+    h->st.dcur ^= 1;           // the gather wrote the diagonal blocks' live copies, with its pair applied, to the other buffer
     h->npend += 1;
     const int32_t rc = (h->npend - h->nfrozen) >= h->batch ? batch_complete(h) : EKF_OK;
     h->hint_idx = -1;          // a hint speaks of the correction that follows THIS one only
@@ -663,10 +660,6 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     static const bool fuse_small = ekf_tune_int("EKF_FUSE_SMALL", 1) != 0;
     const bool fused = fuse_small && h->batch == 1 && !h->async_flush && h->npend == 0 && a.n_mm <= gather_fuse_max_rows() &&
                        ekf_tiles_for(a.n_mm, h->T) * h->T <= 256;
-    if (fused) {                     // this launch is also a pass over P: it gets a number like the others (F32 tile rounding)
-        if (++h->pass_seq == 0u) h->pass_seq = 1u;
-        h->st.tm.pass = h->cfg.f32_rounding == 1 ? 0u : h->pass_seq;
-    }
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
@@ -675,6 +668,7 @@ int32_t do_correct(ekf_handle *h, const double z[2], const double R[4], int64_t 
     }
     if (fused) {                     // the pair never became pending: nothing to flush, only the double buffers flip
         h->cur ^= 1;
+        h->st.dcur ^= 1;
         snprintf(h->dd_kernel, sizeof h->dd_kernel, "k_gather<%s,fused downdate>", h->storage == EKF_STORE_F64 ? "double" : "float");
         h->dd_pairs = 1;
         return throttle_step(h);
@@ -1009,7 +1003,9 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         HIPCHK(h, dalloc(h, &h->st.x[b], (size_t)(3 + ldm)));
         HIPCHK(h, dalloc(h, &h->st.prr[b], 16));
         HIPCHK(h, dalloc(h, &h->st.strip[b], (size_t)(3 * ldm)));
+        HIPCHK(h, dalloc(h, &h->st.diag[b], (size_t)(3 * h->cap)));       // live F64 copies of the 2x2 diagonal blocks (kernels.h)
     }
+    h->st.dcur = 0;
     {
         char *tiles = nullptr;
         HIPCHK(h, dalloc(h, &tiles, (size_t)slots * T * T * elt_size(h)));
@@ -1699,8 +1695,7 @@ struct CkptHeader {
     int64_t N;
     int32_t tile, storage, world, rank;
     int64_t tile_bytes;      // bytes of the tile section
-    int64_t pass_seq;        // passes over P so far (seeds the rounding of F32 tile stores: a resumed run continues bit for bit)
-    int64_t reserved[2];
+    int64_t reserved[3];
 };
 static_assert(sizeof(CkptHeader) == 64, "checkpoint header is 64 bytes");
 
@@ -1743,16 +1738,16 @@ int32_t ekf_checkpoint_save(ekf_handle *h, const char *path) {
     const int64_t nmm = n_mm(h), nt = ekf_tiles_for(nmm, h->T);
     CkptHeader hd;
     memset(&hd, 0, sizeof hd);
-    memcpy(hd.magic, "EKFSLAM1", 8);
+    memcpy(hd.magic, "EKFSLAM2", 8);
     hd.N = h->N; hd.tile = h->T; hd.storage = h->storage; hd.world = h->cfg.world; hd.rank = h->cfg.rank;
     hd.tile_bytes = h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h);
-    hd.pass_seq = (int64_t)h->pass_seq;
     rc = fwrite(&hd, sizeof hd, 1, f) == 1 ? EKF_OK : fail(h, EKF_ERR_STATE, "checkpoint: short write");
     if (!rc) rc = stream_out(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);
     if (!rc && h->N > 0) rc = stream_out(h, f, h->st.s, (size_t)h->N * 8, stage, stage_bytes);
     if (!rc) rc = stream_out(h, f, h->st.prr[h->cur], 9 * 8, stage, stage_bytes);
     for (int r = 0; r < 3 && !rc && nmm > 0; ++r)
         rc = stream_out(h, f, h->st.strip[h->cur] + (size_t)r * h->st.ldm, (size_t)nmm * 8, stage, stage_bytes);
+    if (!rc && h->N > 0) rc = stream_out(h, f, h->st.diag[h->st.dcur], (size_t)(3 * h->N) * 8, stage, stage_bytes);
     if (!rc && hd.tile_bytes > 0) rc = stream_out(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
     hipHostFree(stage);
     if (fclose(f) != 0 && !rc) rc = fail(h, EKF_ERR_STATE, "checkpoint: close failed");
@@ -1769,15 +1764,15 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     // every exit below goes through here: the file is closed and the staging buffer released whatever happened
     auto done = [&](int32_t status) { if (stage) hipHostFree(stage); fclose(f); return status; };
     CkptHeader hd;
-    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM1", 8) != 0)
-        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM1 file"));
+    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM2", 8) != 0)
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM2 file"));
     if (hd.tile != h->T || hd.storage != h->storage || hd.world != h->cfg.world || hd.rank != h->cfg.rank || hd.N < 0 || hd.N > h->cap)
         return done(fail(h, EKF_ERR_STATE, "checkpoint_load: tile edge, storage, shard or capacity do not match this handle"));
     const int64_t nmm = 2 * hd.N, nt = ekf_tiles_for(nmm, h->T);
     if (hd.tile_bytes != h->st.tm.slots_for_rows(nt) * (int64_t)h->T * h->T * (int64_t)elt_size(h))
         return done(fail(h, EKF_ERR_STATE, "checkpoint_load: tile section size mismatch"));
     // the whole payload must be there BEFORE any device state is overwritten: a truncated file leaves the handle as it was
-    const int64_t payload = (3 + nmm) * 8 + hd.N * 8 + 9 * 8 + 3 * nmm * 8 + hd.tile_bytes;
+    const int64_t payload = (3 + nmm) * 8 + hd.N * 8 + 9 * 8 + 3 * nmm * 8 + 3 * hd.N * 8 + hd.tile_bytes;
     if (fseek(f, 0, SEEK_END) != 0) return done(fail(h, EKF_ERR_STATE, "checkpoint_load: cannot seek"));
     const long fsize = ftell(f);
     if (fsize < 0 || (int64_t)fsize != (int64_t)sizeof hd + payload)
@@ -1801,10 +1796,10 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     if (!rc) rc = stream_in(h, f, h->st.prr[h->cur], 9 * 8, stage, stage_bytes);
     for (int r = 0; r < 3 && !rc && nmm > 0; ++r)
         rc = stream_in(h, f, h->st.strip[h->cur] + (size_t)r * h->st.ldm, (size_t)nmm * 8, stage, stage_bytes);
+    if (!rc && hd.N > 0) rc = stream_in(h, f, h->st.diag[h->st.dcur], (size_t)(3 * hd.N) * 8, stage, stage_bytes);
     if (!rc && hd.tile_bytes > 0) rc = stream_in(h, f, h->st.tiles, (size_t)hd.tile_bytes, stage, stage_bytes);
     // N follows x even when a later section failed (an I/O error mid-way): x and N must never disagree
     h->N = hd.N;
-    h->pass_seq = (uint32_t)hd.pass_seq;
     h->s_host = shost;
     h->s_sorted_ok = false;
     h->work_rows = -1;

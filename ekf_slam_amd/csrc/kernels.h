@@ -36,6 +36,17 @@ struct DevState {
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
     int64_t ldm;       // strip leading dimension = landmark-block capacity rounded up to T
     TileMap tm;
+    // The 2x2 DIAGONAL blocks of the landmark block, kept LIVE in F64 beside the tiles: landmark k's (P(2k,2k), P(2k+1,2k), P(2k+1,2k+1))
+    // at diag[dcur][3k .. 3k+2].  Every correction's gather kernel applies its own pair to them at once (each column lane holds K(c,:)
+    // and G(:,c)) -- the chain base - sum_i K_i G_i in slot order that a reader of the tiles would have to re-run over the pending pairs,
+    // so in F64 the values equal the patched tile entries bit for bit -- reading buffer dcur, writing dcur ^ 1 (flipped per correction,
+    // independently of `cur`: a predict does not touch them).  Why: (1) whoever needs a diagonal block (the correction's own solve, the
+    // association of every landmark) reads three doubles instead of patching a chain of pending pairs; (2) with F32 tiles these are the
+    // LARGE entries of P (an appended, not yet re-observed landmark: ~17 against a bulk of 0.1) whose sub-ulp updates a float store loses
+    // -- in F64 they lose nothing.  Replicated on every shard (the gather is).  The tiles' own copies of these entries keep being
+    // maintained by the passes but are no longer read.
+    double *diag[2];
+    int32_t dcur;
 };
 
 struct CorrectArgs {

@@ -66,31 +66,6 @@ __device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
     return fma(-k.y, g.y, fma(-k.x, g.x, v));       // v - K(r,1) G(1,c) - K(r,2) G(2,c): two FMAs, fixed order
 }
 
-// What a pass over P stores.  F64 tiles: the value.  F32 tiles: the value rounded to float -- STOCHASTICALLY, with a deterministic
-// seed: hash(global row, global column, number of the pass).  Round-to-nearest loses every update that is smaller than half an ulp
-// of the entry it applies to, pass after pass in the same direction (stagnation): on a streaming-append map the large diagonal blocks
-// of not-yet-re-observed landmarks then drift from the F64 result LINEARLY, 1.6e-9 per update-step (profiles/round3_f32_drift.json).
-// Rounding up with probability (v - lo) / (hi - lo) is unbiased, so the same updates accumulate like a random walk instead.  The
-// seed depends on the ELEMENT and the PASS only: every kernel instance (MFMA or VALU flush, any tile edge), every shard layout and
-// every replay of the same run stores the same bits.  A value that is a float already is stored unchanged whatever the seed
-// (its low 29 mantissa bits are zero), so entries a pass does not change stay as they are.
-template <typename TS> __device__ __forceinline__ TS round_tile(double v, uint32_t row, uint32_t col, uint32_t pass);
-template <> __device__ __forceinline__ double round_tile<double>(double v, uint32_t, uint32_t, uint32_t) { return v; }
-template <> __device__ __forceinline__ float round_tile<float>(double v, uint32_t row, uint32_t col, uint32_t pass) {
-    // No early return: a branch here splits the caller's 16-byte tile store into scalar stores (3x slower pass).
-    const unsigned long long b0 = (unsigned long long)__double_as_longlong(v);
-    const uint32_t ex0 = (uint32_t)(b0 >> 52) & 0x7ffu;
-    uint32_t h = row * 0x9E3779B1u ^ (col + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (pass + 0x165667B1u) * 0xC2B2AE35u;    // a full avalanche per element:
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;                                                                 // (a cheaper per-group seed measured no faster)
-    unsigned long long b = b0 + (unsigned long long)(h & 0x1fffffffu);      // 29 = 52 - 23 dropped mantissa bits: carry into the kept ones
-    b &= ~0x1fffffffull;                                                     //   with probability (dropped part) / 2^29, then truncate
-    // round to nearest instead (the conversion below does it on the untouched bits) where asked for (pass 0) and for Inf / NaN;
-    // selects only -- a branch per element (even a wave-uniform, never-taken one) cost the 12-pair flush 0.6 ms of 5
-    b = EKF_SEL((pass == 0u) | (ex0 == 0x7ffu)) ? b0 : b;
-    return (float)__longlong_as_double((long long)b);     // exact for the truncated value (+-Inf past FLT_MAX, as rounding up would give;
-                                                          // below float's normal range the conversion rounds what is left -- zero stays zero)
-}
-
 __device__ __forceinline__ int ring_slot(int pstart, int i, int pcap) { const int s = pstart + i; return s >= pcap ? s - pcap : s; }
 
 // live value of canonical element (r >= c enforced here) = base - sum over pending pairs, in slot order
@@ -115,6 +90,7 @@ __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, i
     if (c < 3) return st.strip[cur][c * st.ldm + (r - 3)];
     int64_t rm = r - 3, cm = c - 3;
     if (rm < cm) { const int64_t t = rm; rm = cm; cm = t; }
+    if ((rm >> 1) == (cm >> 1)) return st.diag[st.dcur][3 * (rm >> 1) + (rm & 1) + (cm & 1)];     // a landmark's own 2x2 block: the live F64 copy
     if (!st.tm.mine(rm >> st.tm.shift, cm >> st.tm.shift)) return NAN;     // held by another shard
     return pmm_low<TS>((const TS *)st.tiles, st.tm, rm, cm);
 }
@@ -396,6 +372,10 @@ __global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, De
         for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) {
             double acc = 0; for (int k = 0; k < 2; ++k) acc += t2[i][k] * jz[j][k]; c2[i][j] = acc; }
         // C: jxr*Prr*jxr' + jz*R*jz' (EKF_SLAM.m:91); only the lower triangle of the 2x2 block is canonical
+        {
+            double *__restrict__ dg = st.diag[st.dcur] + 3 * a.N;        // the new landmark's diagonal block, live F64 copy (every shard)
+            dg[0] = c1[0][0] + c2[0][0]; dg[1] = c1[1][0] + c2[1][0]; dg[2] = c1[1][1] + c2[1][1];
+        }
         if (st.tm.mine(n_mm >> st.tm.shift, n_mm >> st.tm.shift)) {
             pmm_low_store<TS>(tiles, st.tm, n_mm, n_mm, c1[0][0] + c2[0][0]);
             pmm_low_store<TS>(tiles, st.tm, n_mm + 1, n_mm, c1[1][0] + c2[1][0]);
@@ -646,7 +626,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     __shared__ int diag_ready;                      // DIAG -> CHAIN: the patched 2x2 block is in pss[15..18]
     __shared__ int staged_cnt;                      // column wavefronts that have written their share of `upatch` (0..4)
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
-    __shared__ double2 dpatch[kMaxPending * 4];     // the same operands once more, staged by the DIAG wavefront for itself
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0-3 columns, 4 chain, 5 diag, 6 bearing
     const int lane = tid & 63;
@@ -695,21 +674,14 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     if (role >= 4) {
         // =========================================== helper wavefronts ===========================================
         // (1h) the small operands, one per lane: the CHAIN wavefront takes what the previous kernel wrote a moment ago (robot block,
-        //      strip columns j, j+1, pose, landmark: 20 doubles, cache-resident), the DIAG wavefront the landmark's own 2x2 block,
-        //      which comes from the tile store in HBM -- two wavefronts, two load queues, so the chain's sincos starts when the
+        //      strip columns j, j+1, pose, landmark: 20 doubles, cache-resident), the DIAG wavefront the landmark's own 2x2 block
+        //      (the live F64 copy) -- two wavefronts, two load queues, so the chain's sincos starts when the
         //      POSE has arrived, not when the slowest of 24 loads has (vector-memory results return in order per wavefront).
         //      Unconditional selected addresses, see the column path.
         // Synchronisation: ONE early hardware barrier ("0", right after everyone has REQUESTED its loads, so that the two LDS flags
         // below are known to be reset) and one at the end ("B").  In between the wavefronts meet through LDS flags only, each waiting
-        // for exactly what it needs: CHAIN and BEARING for their own loads, DIAG for the column wavefronts' staging of `upatch`.
+        // for exactly what it needs: CHAIN, BEARING and DIAG for their own loads.
         double small_v = 0.0;
-        auto load_up_h = [&](int e0) {                                   // as the column path's load_up: clamped, unconditional
-            const int e = (do_patch && e0 < 4 * npend) ? e0 : 0;
-            const int i = e >> 2, which = e & 3;
-            const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
-            return reinterpret_cast<const double2 *>(base)[j + (which & 1)];
-        };
-        double2 dup0 = make_double2(0.0, 0.0), dup1 = dup0;
         if (role == 4) {
             const double *sp = prr_cur;                                  // idle lanes re-read Prr(1,1), unused
             if (lane < 9) sp = prr_cur + lane;
@@ -719,20 +691,11 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             small_v = *sp;
             if (lane == 24) { diag_ready = 0; staged_cnt = 0; }
         } else if (role == 5) {
-            const int t = (lane >> 1) & 1, b = lane & 1;                 // lanes 0..3: canonical P(j+t, j+b)
-            if (kSharded) {
-                const double2 mj = pv.at(st.tm, j), mj1 = pv.at(st.tm, j + 1);
-                small_v = (t == 0 && b == 0) ? mj.x : (t == 1 && b == 1) ? mj1.y : mj.y;
-            } else {
-                // canonical entry: row j + max(t,b), column j + min(t,b), all inside the (uniform) diagonal tile of j
-                const int64_t Ij = j >> st.tm.shift, jm = j & (st.tm.T - 1);
-                const int rr = t > b ? t : b, cc2 = t > b ? b : t;
-                small_v = (double)tiles[st.tm.tile_offset(Ij, Ij) + ((jm + rr) << st.tm.shift) + jm + cc2];
-            }
-            // ... and the wave-uniform operands of the first 32 pending pairs (two per lane), so that the patch chain below does not
-            // wait for the column wavefronts' staging of `upatch` (it used to start ~1 000 clocks later and, at 16+ pending pairs,
-            // made the CHAIN wait for it)
-            dup0 = load_up_h(lane); dup1 = load_up_h(lane + 64);
+            // lanes 0..3: canonical P(j+t, j+b) of the landmark's own 2x2 block -- from the LIVE F64 copy (DevState::diag): every
+            // correction so far has applied its pair to it already, so there is no chain of pending pairs to re-run here (that chain,
+            // serial in slot order, was what bounded this kernel from ~28 pending pairs on)
+            const int t = (lane >> 1) & 1, b = lane & 1;
+            small_v = st.diag[st.dcur][3 * (j >> 1) + (t > b ? t : b) + (t > b ? b : t)];
         } else {
             small_v = x[lane < 3 ? lane : 3 + j + ((lane - 3) & 1)];       // BEARING: lanes 0..2 the pose, 3..4 the landmark
         }
@@ -743,33 +706,9 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         if (role == 5 && lane < 4) pss[15 + lane] = small_v;
         EKF_STAMP();                                                  // 2: own operands arrived
         if (role == 5) {
-            // ---- DIAG: canonical (j,j), (j+1,j), (j+1,j+1) on three lanes; operands are the staged ones, read 8 pairs at a time so
-            //      that the LDS latency is paid per group, not per pair
-            if (do_patch && npend > 0) {
-                dpatch[lane] = dup0; dpatch[lane + 64] = dup1;        // pairs 0..31; more than 32 pending (asynchronous flush): the rest now
-                for (int e = 128 + lane; e < 4 * npend; e += 64) dpatch[e] = load_up_h(e);
-                wave_lds_sync();
-                EKF_STAMP();                                          // (probe, DIAG view) operands staged
-                if (lane < 3) {
-                    const int q = lane;
-                    const int ka = q == 0 ? 0 : 1, ga = q == 2 ? 3 : 2;
-                    double d = pss[q == 0 ? 15 : q == 1 ? 17 : 18];
-                    // the chain itself: two dependent FMAs per pending pair, in slot order; operands of 8 pairs read from LDS at a
-                    // time, whole groups first (no clamps, no selects in the chain), then the remainder pair by pair
-                    int i = 0;
-                    for (; i + 8 <= npend; i += 8) {
-                        double2 kk[8], gg[8];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) { kk[t] = dpatch[4 * (i + t) + ka]; gg[t] = dpatch[4 * (i + t) + ga]; }
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) d = rank2_apply(d, kk[t], gg[t]);
-                    }
-                    for (; i < npend; ++i) d = rank2_apply(d, dpatch[4 * i + ka], dpatch[4 * i + ga]);
-                    if (q == 0) pss[15] = d; else if (q == 1) { pss[16] = d; pss[17] = d; } else pss[18] = d;
-                }
-            }
-            wave_lds_sync();                                              // the (patched) block is written ...
-            if (lane == 0) *(volatile int *)&diag_ready = 1;              // ... before the flag (one wavefront: LDS order = program order)
+            // ---- DIAG: the block is in pss[15..18] (written above): tell the CHAIN wavefront
+            wave_lds_sync();
+            if (lane == 0) *(volatile int *)&diag_ready = 1;              // (one wavefront: LDS order = program order)
             EKF_STAMP();                                                  // (probe, DIAG view) flag set
         } else if (role == 6) {
             // ---- BEARING: nu = z - z_k, z_k = [sqrt(q); wrapTo360(atan2d(dy,dx) - heading)]  (EKF_SLAM.m:125-130,144), from the
@@ -949,6 +888,14 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         s0 = strip[c]; s1 = strip[ldm + c]; s2 = strip[2 * ldm + c];
         xc = x[3 + c];
     }
+    // the column's own diagonal-block entries, live F64 copies (DevState::diag): even columns hold (2k,2k), odd ones (2k+1,2k) and
+    // (2k+1,2k+1).  Read for three purposes: rows j, j+1 at columns j, j+1 ARE these entries (below); this correction's pair is
+    // applied to them at the end of the kernel; and the kDev epilogue's association starts from the result.
+    double dgc = 0.0, dgl = 0.0;
+    if (live) {
+        const double *__restrict__ dg = st.diag[st.dcur] + 3 * (c >> 1);
+        if (c & 1) { dgl = dg[1]; dgc = dg[2]; } else dgc = dg[0];
+    }
     __builtin_amdgcn_sched_barrier(0);
     EKF_STAMP();                                                  // b: all loads requested
     // (2) stage the uniform operands (waits for the FIRST group of loads only); the four column wavefronts and DIAG meet on a
@@ -966,14 +913,11 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     //     the helper wavefronts -- the critical path -- spent waiting for them; behind it the column lanes have ~3 000 clocks of
     //     slack until the solve is published (scripts/probe_gather_phases.py).
     // 32 pairs: a 64-pair variant (344 VGPRs, one workgroup per CU) was slower under an asynchronous flush (tuning log, sweep 12)
-    // (the device-loop instance splits the same registers: 16 pairs of this operand + 16 of the complementary one its epilogue needs)
-    constexpr int kPre = kDev ? 16 : 32;
+    constexpr int kPre = 32;
     const int npre = do_patch ? (npend < kPre ? npend : kPre) : 0;
     const int64_t pad_cols = st.tm.padded(a.n_mm);
     const int64_t ps2 = st.pair_stride / 2;
     double2 pre[kPre];
-    double2 oth[kDev ? kPre : 1];                                 // kDev: the OTHER operand of the same pairs (K_i(c,:) left of j, G_i(:,c) right)
-    double dcc = 0.0, dlo = 0.0;                                  // kDev: base of the column's own diagonal entry (and, odd columns, the one left of it)
     bool next_assoc = false;
     if constexpr (kDev) next_assoc = dl.parts_out != nullptr;
     {
@@ -986,7 +930,6 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         const uint32_t lane_off = cc + (rowpart ? 0u : krel);
         const char *__restrict__ ub = reinterpret_cast<const char *>(st.Gp);
         const uint32_t lane_bytes = lane_off * 16u;              // < 2^32: see below
-        const uint32_t oth_bytes = (cc + (rowpart ? krel : 0u)) * 16u;
         // slot offsets advance incrementally around the ring (scalar unit: one add, one wrap test per pair)
         // (32-bit: 2 * pcap * pair_stride / 2 <= 256 * 2 * capacity elements of 16 bytes stays far below 2^32)
         const uint32_t step = (uint32_t)ps2, wrap = (uint32_t)st.pcap * step;
@@ -1002,22 +945,12 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     pre[g0 + t] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + lane_bytes);
-                    if constexpr (kDev) oth[g0 + t] = *reinterpret_cast<const double2 *>(ub + (uint64_t)off * 16u + oth_bytes);
                     if (g0 + t + 1 < npre) { off += step; if (off == wrap) off = 0; }
                 }
             }
         }
     }
 
-
-    if constexpr (kDev) {
-        // the epilogue's own diagonal entries, requested now (tile store: the one HBM-latency load of the epilogue); clamped,
-        // unconditional: canonical (2k,2k) on even columns, (2k+1,2k) and (2k+1,2k+1) -- one load -- on odd ones
-        const int64_t cl = live ? c : (c & 1);
-        if (c & 1) pmm_low_pair<TS>(tiles, st.tm, cl, cl - 1, dlo, dcc);
-        else dcc = pmm_low<TS>(tiles, st.tm, cl, cl);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 
     // (3) every lane applies the pending pairs to its own two row entries while the helper wavefronts run the solve
     if (live && do_patch) {
@@ -1089,44 +1022,12 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             }
         }
     }
-    if constexpr (kDev) {
-        // ... and, while the helper wavefronts still run the solve, the pending pairs on the epilogue's diagonal entries (dcc; odd
-        // columns also dlo, the one left of it), in slot order (pmm_live's chain, as k_associate runs it): everything of the next
-        // observation's association that does not depend on this correction.  The first kPre pairs' operands are in registers:
-        // `pre` holds G_i(:,c) left of j and K_i(c,:) right of it, `oth` the other one.
-        if (next_assoc) {
-            const int64_t cl = live ? c : (c & 1);                // clamped: unconditional loads, no shuffles under divergence
-#pragma unroll
-            for (int g0 = 0; g0 < kPre; g0 += 8)
-                if (g0 < npre) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const double2 kc = rowpart ? oth[g0 + t] : pre[g0 + t], gc = rowpart ? pre[g0 + t] : oth[g0 + t];
-                        const double2 gl = make_double2(__shfl_xor(gc.x, 1), __shfl_xor(gc.y, 1));   // the partner column's G_i
-                        const double v0 = rank2_apply(dcc, kc, gc), v1 = rank2_apply(dlo, kc, gl);      // dlo, odd lanes: K_i(2k+1,:) G_i(:,2k)
-                        dcc = g0 + t < npre ? v0 : dcc; dlo = g0 + t < npre ? v1 : dlo;
-                    }
-                }
-            // more than kPre pending pairs: 8 pairs' operands in flight together, applied in order
-            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + cl;
-            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + cl;
-            for (int i0 = npre; i0 < npend; i0 += 8) {
-                double2 kk[8], gg[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int64_t so = (int64_t)ring_slot(pstart, i0 + q < npend ? i0 + q : npend - 1, st.pcap) * ps2;
-                    kk[q] = kp[so]; gg[q] = gp[so];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const double2 gl = make_double2(__shfl_xor(gg[q].x, 1), __shfl_xor(gg[q].y, 1));
-                    if (i0 + q < npend) {
-                        dcc = rank2_apply(dcc, kk[q], gg[q]);
-                        dlo = rank2_apply(dlo, kk[q], gl);
-                    }
-                }
-            }
-        }
+    // rows j, j+1 at columns j and j+1 are the landmark's own diagonal block: the live F64 copies (no pending pair to apply; the same bits
+    // as the patched tile entries with F64 tiles, the unrounded values with F32 tiles)
+    {
+        const double dgl_p = __shfl_xor(dgl, 1);                   // the odd partner's (2k+1, 2k)
+        if (c == j) { m0 = dgc; m1 = dgl_p; }                      // P(j, j), P(j+1, j)
+        else if (c == j + 1) { m0 = dgl; m1 = dgc; }               // P(j+1, j), P(j+1, j+1)
     }
     EKF_STAMP();                                                  // 2: patches done
     __syncthreads();                                              // barrier B: the helpers' results are in LDS
@@ -1163,6 +1064,19 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
     }
+    // (4b) this correction's pair on the diagonal blocks, at once: P(I - K H) restricted to each landmark's own 2x2 block, rank2_apply in
+    //      slot order like every pass -- the live copies never carry a pending pair.  ndc = the column's (c,c), ndl = (2k+1, 2k) on odd columns.
+    double ndc, ndl;
+    {
+        const double2 kn = make_double2(k0, k1), gn = make_double2(g[0], g[1]);
+        const double2 gl = make_double2(__shfl_xor(gn.x, 1), __shfl_xor(gn.y, 1));       // the partner column's G (odd lanes: G(:, 2k))
+        ndc = rank2_apply(dgc, kn, gn);
+        ndl = rank2_apply(dgl, kn, gl);
+        if (live) {
+            double *__restrict__ dn = st.diag[st.dcur ^ 1] + 3 * (c >> 1);
+            if (c & 1) { dn[1] = ndl; dn[2] = ndc; } else dn[0] = ndc;
+        }
+    }
     if (kFused) {
         // P = (I - K H) P on the landmark block, here: one workgroup holds every K(r,:) and G(:,c).  K goes through LDS (`upatch` is
         // free: the patches that read it are behind barrier B; the helper wavefronts have left, a barrier counts live wavefronts
@@ -1192,25 +1106,19 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             }
 #pragma unroll
             for (int q = 0; q < kFuseElems; ++q)
-                if (ptr[q]) *ptr[q] = round_tile<TS>(rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]), rr[q], cq[q], st.tm.pass);
+                if (ptr[q]) *ptr[q] = (TS)rank2_apply(val[q], upatch[rr[q]], upatch[kGatherCols + cq[q]]);
         }
     }
     if constexpr (kDev) {
         if (next_assoc) {                                         // uniform
             // ---- the NEXT observation's association (Correspondence.m:49-87) on the state this correction leaves.  Landmark
             //      k = c / 2 is scored by its even column lane; everything it needs is in this lane pair's registers (x', strip',
-            //      this correction's K(c,:), G(:,c)) or in the workgroup's LDS (Prr before the correction, K_r, G_r, nu) -- except
-            //      the base value of its own 2x2 block and the pending pairs' operands at its columns (L2-resident).
+            //      the landmark's own 2x2 block after this correction) or in the workgroup's LDS (Prr before the correction, K_r,
+            //      G_r, nu).
             __shared__ double na_ll[kGatherCols / 64];
             __shared__ int na_ix[kGatherCols / 64];
             const bool odd = (c & 1) != 0;
-            {
-                // the column's diagonal entries carry the pending pairs already (before barrier B); now this correction's own pair (ring position npend), from registers
-                const double2 kn = make_double2(k0, k1), gn = make_double2(g[0], g[1]);
-                const double2 gl = make_double2(__shfl_xor(gn.x, 1), __shfl_xor(gn.y, 1));
-                dcc = rank2_apply(dcc, kn, gn);
-                dlo = rank2_apply(dlo, kn, gl);
-            }
+            const double dcc = ndc, dlo = ndl;                    // the landmark's own block after this correction: computed above, live
             // odd lane -> even lane
             const double xn_o = __shfl_xor(xn, 1), t0_o = __shfl_xor(t0, 1), t1_o = __shfl_xor(t1, 1), t2_o = __shfl_xor(t2, 1),
                          d10 = __shfl_xor(dlo, 1), d11 = __shfl_xor(dcc, 1);
@@ -1329,8 +1237,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate(const TS *__restrict__ tile
             const int r = r0 + p * kRowsPerPass;
             if (kExact || r < kSlab) {
                 V2 o;
-                const uint32_t grow = (uint32_t)(ij.x * T + slab * kSlab + r), gcl = (uint32_t)(ij.y * T + 2 * cp);
-                o.x = round_tile<TS>(v[p].x, grow, gcl, tm.pass); o.y = round_tile<TS>(v[p].y, grow, gcl + 1u, tm.pass);
+                o.x = (TS)v[p].x; o.y = (TS)v[p].y;
                 *reinterpret_cast<V2 *>(td + r * T + 2 * cp) = o;
             }
         }
@@ -1348,10 +1255,9 @@ template <> struct Lane16<double> { using type = double2; static constexpr int k
 template <> struct Lane16<float>  { using type = float4;  static constexpr int kCols = 4; };
 __device__ __forceinline__ void lane16_unpack(const double2 &t, double *v) { v[0] = t.x; v[1] = t.y; }
 __device__ __forceinline__ void lane16_unpack(const float4 &t, double *v) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-__device__ __forceinline__ void lane16_pack(const double *v, double2 &t, uint32_t, uint32_t, uint32_t) { t.x = v[0]; t.y = v[1]; }
-__device__ __forceinline__ void lane16_pack(const double *v, float4 &t, uint32_t row, uint32_t col, uint32_t pass) {
-    t.x = round_tile<float>(v[0], row, col, pass); t.y = round_tile<float>(v[1], row, col + 1u, pass);
-    t.z = round_tile<float>(v[2], row, col + 2u, pass); t.w = round_tile<float>(v[3], row, col + 3u, pass);
+__device__ __forceinline__ void lane16_pack(const double *v, double2 &t) { t.x = v[0]; t.y = v[1]; }
+__device__ __forceinline__ void lane16_pack(const double *v, float4 &t) {
+    t.x = (float)v[0]; t.y = (float)v[1]; t.z = (float)v[2]; t.w = (float)v[3];
 }
 __device__ __forceinline__ double lane16_get(const double2 &t, int q) { return q == 0 ? t.x : t.y; }
 __device__ __forceinline__ double lane16_get(const float4 &t, int q) { return (double)(q == 0 ? t.x : q == 1 ? t.y : q == 2 ? t.z : t.w); }
@@ -1461,7 +1367,7 @@ __global__ __launch_bounds__(kBlock) void k_downdate_w(const TS *__restrict__ ti
         VL stored[kPasses];
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
-            lane16_pack(v[p], stored[p], (uint32_t)(ij.x * T + row0 + sub + p * kRowsPerInstr), (uint32_t)(ij.y * T + kCols * cl), tm.pass);
+            lane16_pack(v[p], stored[p]);
             *reinterpret_cast<VL *>(td + (int64_t)p * kRowsPerInstr * T) = stored[p];
         }
         if constexpr (kNext) {
@@ -1521,7 +1427,6 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
     if (k < a.N) {
         const double *__restrict__ x = st.x[cur];
         const double *__restrict__ strip = st.strip[cur];
-        const TS *__restrict__ tiles = (const TS *)st.tiles;
         const int64_t j = 2 * k;
         double pss[24];
         for (int i = 0; i < 9; ++i) pss[i] = kPredict ? aps.prr[i] : st.prr[cur][i];
@@ -1539,36 +1444,13 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate(DevState st, AssocArg
                 for (int i = 0; i < 3; ++i) xn[i] = aps.pose[i];
             }
         }
-        // the 2x2 diagonal block lives in a diagonal tile; on another shard's tile the position cost is NaN
-        // (the reference's decision is signature-only, Correspondence.m:75, so it is unaffected)
+        // the landmark's own 2x2 block: the live F64 copy (DevState::diag) -- every correction so far has applied its pair to it, on
+        // every shard, so there is neither a chain of pending pairs to run here nor a tile another shard holds.  have_diag (does this
+        // shard hold the landmark's diagonal TILE) only decides which shard nominates the landmark in a sharded association's exchange.
         const bool have_diag = st.tm.mine(j >> st.tm.shift, j >> st.tm.shift);
-        if (have_diag) {
-            // live canonical (j,j), (j+1,j), (j+1,j+1): base values minus the pending pairs in slot order (= pmm_live), with
-            // the operands of 4 pairs (16 loads) in flight together instead of one dependent round trip per pair and entry
-            double d00, d10, d11;
-            d00 = pmm_low<TS>(tiles, st.tm, j, j);
-            pmm_low_pair<TS>(tiles, st.tm, j + 1, j, d10, d11);
-            const int64_t ps2 = st.pair_stride / 2;
-            const double2 *__restrict__ kp = reinterpret_cast<const double2 *>(st.Kp) + j;
-            const double2 *__restrict__ gp = reinterpret_cast<const double2 *>(st.Gp) + j;
-            for (int i0 = 0; i0 < a.npend; i0 += 4) {
-                double2 k0[4], k1[4], g0[4], g1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int64_t so = (int64_t)ring_slot(a.pstart, i0 + q < a.npend ? i0 + q : a.npend - 1, st.pcap) * ps2;
-                    k0[q] = kp[so]; k1[q] = kp[so + 1]; g0[q] = gp[so]; g1[q] = gp[so + 1];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (i0 + q < a.npend) {
-                        d00 = rank2_apply(d00, k0[q], g0[q]);
-                        d10 = rank2_apply(d10, k1[q], g0[q]);
-                        d11 = rank2_apply(d11, k1[q], g1[q]);
-                    }
-            }
-            pss[15] = d00; pss[16] = d10; pss[17] = d10; pss[18] = d11;
-        } else {
-            pss[15] = pss[16] = pss[17] = pss[18] = NAN;
+        {
+            const double *__restrict__ dg = st.diag[st.dcur] + 3 * k;
+            pss[15] = dg[0]; pss[16] = dg[1]; pss[17] = dg[1]; pss[18] = dg[2];
         }
         for (int i = 0; i < 3; ++i) pss[19 + i] = kPredict ? aps.pose[i] : x[i];
         pss[22] = x[3 + j]; pss[23] = x[3 + j + 1];
@@ -1700,6 +1582,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_dense(DevState st, int cur, int
     if (r < 3) { st.prr[cur][3 * r + c] = v; st.prr[cur][3 * c + r] = v; return; }
     if (c < 3) { st.strip[cur][c * st.ldm + (r - 3)] = v; return; }
     const int64_t rm = r - 3, cm = c - 3;
+    if ((rm >> 1) == (cm >> 1)) st.diag[st.dcur][3 * (rm >> 1) + (rm & 1) + (cm & 1)] = v;        // (every shard: the diagonal blocks are replicated)
     if (st.tm.mine(rm >> st.tm.shift, cm >> st.tm.shift)) pmm_low_store<TS>((TS *)st.tiles, st.tm, rm, cm, v);
 }
 
@@ -1758,6 +1641,12 @@ __global__ __launch_bounds__(kBlock) void k_lowrank_robot(DevState st, int cur, 
             for (int64_t q = 0; q < k; ++q) v += U[q * n + r] * U[q * n + 3 + c];
             st.strip[cur][r * st.ldm + c] = v;
         }
+        // the landmark's own diagonal-block entries: the arithmetic of k_lowrank_tiles, in F64
+        double *__restrict__ dg = st.diag[st.dcur] + 3 * (c >> 1);
+        double vcc = 0.0, vlo = 0.0;
+        for (int64_t q = 0; q < k; ++q) { vcc += U[q * n + 3 + c] * U[q * n + 3 + c]; if (c & 1) vlo += U[q * n + 3 + c] * U[q * n + 3 + c - 1]; }
+        vcc += d[3 + c];
+        if (c & 1) { dg[1] = vlo; dg[2] = vcc; } else dg[0] = vcc;
     }
     if (c == 0) {
         for (int r = 0; r < 3; ++r) for (int b = 0; b < 3; ++b) {
@@ -1793,7 +1682,7 @@ __global__ __launch_bounds__(kBlock) void k_digest(DevState st, int cur, int64_t
             const int rr = e >> st.tm.shift, cc = e & (T - 1);
             const int64_t r = (int64_t)ij.x * T + rr, c = (int64_t)ij.y * T + cc;
             if (r < n_mm && c <= r) {
-                const double v = (double)tp[e];
+                const double v = ((r >> 1) == (c >> 1)) ? st.diag[st.dcur][3 * (r >> 1) + (r & 1) + (c & 1)] : (double)tp[e];
                 sm += v; sq += v * v;
                 if (r == c) tr += v;
             }
@@ -2073,29 +1962,15 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
             }
         }
         typedef TS store16_t __attribute__((ext_vector_type(kE)));                  // the lane's 16 bytes of a row: ONE store instruction
-        if (sizeof(TS) == 8 || tm.pass == 0u) {                                     // (uniform) plain stores: F64 tiles, or F32 rounded to nearest
 #pragma unroll
-            for (int bp = 0; bp < kBP; ++bp)
+        for (int bp = 0; bp < kBP; ++bp)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    store16_t o;
+            for (int r = 0; r < 4; ++r) {
+                store16_t o;
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) o[e] = (TS)acc[bp][e][r];
-                    __builtin_nontemporal_store(o, reinterpret_cast<store16_t *>(td + (int64_t)(4 * r) * T + 16 * kE * bp));
-                }
-        } else {
-#pragma unroll
-            for (int bp = 0; bp < kBP; ++bp)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    store16_t o;
-#pragma unroll
-                    for (int e = 0; e < kE; ++e)
-                        o[e] = round_tile<TS>(acc[bp][e][r], (uint32_t)(ij.x * T + row0 + lr + 4 * r),
-                                              (uint32_t)(ij.y * T + cpart * kCols + 16 * kE * bp + kE * lc + e), tm.pass);
-                    __builtin_nontemporal_store(o, reinterpret_cast<store16_t *>(td + (int64_t)(4 * r) * T + 16 * kE * bp));
-                }
-        }
+                for (int e = 0; e < kE; ++e) o[e] = (TS)acc[bp][e][r];
+                __builtin_nontemporal_store(o, reinterpret_cast<store16_t *>(td + (int64_t)(4 * r) * T + 16 * kE * bp));
+            }
     }
 }
 

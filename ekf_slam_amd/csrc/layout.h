@@ -29,8 +29,6 @@ struct TileMap {
     int32_t world;   // shards
     int32_t rank;    // this shard
     int32_t reverse = 0;   // pass kernels only: walk the work list backwards (set on alternate passes, abi.hip::next_pass_direction)
-    uint32_t pass = 0;     // pass kernels only, F32 tiles: number of this pass over P (seeds the stochastic rounding of the stores,
-                           // kernels.hip::round_tile); 0 = round to nearest
 
     // Tile indices are small non-negative numbers: all index arithmetic is 32-bit unsigned (a 64-bit integer division is
     // a ~100-instruction sequence on the GPU and these run in the latency-critical prologue of every gather), and a single

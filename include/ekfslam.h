@@ -104,11 +104,7 @@ typedef struct ekf_config {
                                     on-die), forwards otherwise; 1 = always forwards; 2 = always alternate.  Same bits. */
     int32_t force_sharded;       /* 1: run the sharded code path (row-panel extraction, exchange, sharded gather) although
                                     world == 1 -- how that path is exercised and timed on a single GPU */
-    int32_t f32_rounding;        /* EKF_STORE_F32 only -- how a pass over P rounds what it stores: 0 (default) = stochastically, seeded by
-                                    (element, number of the pass): unbiased, deterministic, the same bits from every kernel instance /
-                                    shard layout / replay; 1 = to nearest (rounds 1-2: updates smaller than half an ulp of an entry are
-                                    lost pass after pass and the landmark block drifts linearly from the F64 result) */
-    int32_t reserved[2];
+    int32_t reserved[3];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;

@@ -26,7 +26,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--storage", default="f32")
-    ap.add_argument("--f32-rounding", type=int, default=0, help="cfg.f32_rounding: 0 stochastic (default), 1 to nearest")
     args = ap.parse_args()
     from ekf_slam_amd import Engine, _lib as L
     from ekf_slam_amd.world import World
@@ -39,7 +38,7 @@ def main():
     d = rng.uniform(0.01, 0.1, n0)
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
-    e = Engine(mode="known", capacity=cap, storage=args.storage, batch=args.batch, f32_rounding=args.f32_rounding)
+    e = Engine(mode="known", capacity=cap, storage=args.storage, batch=args.batch)
     t0 = time.perf_counter()
     e.load_lowrank_state(x, s, d, U)
     e.sync()
@@ -82,7 +81,7 @@ def main():
            "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s tiles" % args.storage, "data": "synthetic",
            "config": {"workload": "configs[4] shape on 1 GPU: %d -> %d landmarks, %s tile storage, F64 solve, step = predict + "
                                   "append + 1 correction (streaming landmark append)" % (N0 + args.warmup, e_N[0], args.storage),
-                      "deferred_batch": args.batch, "f32_rounding": "nearest" if args.f32_rounding else "stochastic", "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
+                      "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
                       "bulk_load_s": t_load, "state_finite": finite},
            "roofline": {"bound": "hbm", "achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s",
                         "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": kernel, "pairs_per_launch": kpairs,

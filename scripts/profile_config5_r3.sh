@@ -1,12 +1,12 @@
 #!/bin/bash
-# GPU box: configs[4] shape on one GPU, both roundings of the F32 tile stores (profiles/round3_config5_1gpu.json)
+# GPU box: configs[4] shape on one GPU, F32 tile storage (profiles/round3_config5_1gpu.json)
 set -e -o pipefail
 OUT=gpurun_out/${1:-r3c5}
 mkdir -p $OUT
-for r in 0 1; do
-  python scripts/bench_config5.py --batch 1 --steps 96 --warmup 16 --f32-rounding $r > $OUT/c5_40k_b1_r$r.json 2>/dev/null
-  python scripts/bench_config5.py --batch 12 --steps 384 --f32-rounding $r > $OUT/c5_40k_b12_r$r.json 2>/dev/null
-  python scripts/bench_config5.py --batch 32 --steps 512 --f32-rounding $r > $OUT/c5_40k_b32_r$r.json 2>/dev/null
+for r in 0; do
+  python scripts/bench_config5.py --batch 1 --steps 96 --warmup 16 > $OUT/c5_40k_b1_r$r.json 2>/dev/null
+  python scripts/bench_config5.py --batch 12 --steps 384 > $OUT/c5_40k_b12_r$r.json 2>/dev/null
+  python scripts/bench_config5.py --batch 32 --steps 512 > $OUT/c5_40k_b32_r$r.json 2>/dev/null
 done
 python scripts/bench_config5.py --landmarks 49400 --batch 12 --steps 384 > $OUT/c5_50k_b12_r0.json 2>/dev/null
 python scripts/bench_config5.py --landmarks 49400 --batch 1 --steps 64 --warmup 16 > $OUT/c5_50k_b1_r0.json 2>/dev/null
