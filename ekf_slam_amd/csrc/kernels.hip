@@ -599,6 +599,12 @@ __device__ __forceinline__ double lane_gather(double v, int src) {       // valu
     const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+// value of the neighbouring lane (lane ^ 1): a DPP quad permutation [1,0,3,2] -- two VALU moves, no LDS crossbar round trip (what
+// __shfl_xor's ds_bpermute costs at the tail of this kernel's latency chain)
+__device__ __forceinline__ double lane_xor1(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 // LDS traffic of ONE wavefront is ordered; this only keeps the compiler from moving accesses across it and drains the queue
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -1025,7 +1031,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     // rows j, j+1 at columns j and j+1 are the landmark's own diagonal block: the live F64 copies (no pending pair to apply; the same bits
     // as the patched tile entries with F64 tiles, the unrounded values with F32 tiles)
     {
-        const double dgl_p = __shfl_xor(dgl, 1);                   // the odd partner's (2k+1, 2k)
+        const double dgl_p = lane_xor1(dgl);                   // the odd partner's (2k+1, 2k)
         if (c == j) { m0 = dgc; m1 = dgl_p; }                      // P(j, j), P(j+1, j)
         else if (c == j + 1) { m0 = dgl; m1 = dgc; }               // P(j+1, j), P(j+1, j+1)
     }
@@ -1069,7 +1075,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
     double ndc, ndl;
     {
         const double2 kn = make_double2(k0, k1), gn = make_double2(g[0], g[1]);
-        const double2 gl = make_double2(__shfl_xor(gn.x, 1), __shfl_xor(gn.y, 1));       // the partner column's G (odd lanes: G(:, 2k))
+        const double2 gl = make_double2(lane_xor1(gn.x), lane_xor1(gn.y));       // the partner column's G (odd lanes: G(:, 2k))
         ndc = rank2_apply(dgc, kn, gn);
         ndl = rank2_apply(dgl, kn, gl);
         if (live) {
@@ -1120,8 +1126,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
             const bool odd = (c & 1) != 0;
             const double dcc = ndc, dlo = ndl;                    // the landmark's own block after this correction: computed above, live
             // odd lane -> even lane
-            const double xn_o = __shfl_xor(xn, 1), t0_o = __shfl_xor(t0, 1), t1_o = __shfl_xor(t1, 1), t2_o = __shfl_xor(t2, 1),
-                         d10 = __shfl_xor(dlo, 1), d11 = __shfl_xor(dcc, 1);
+            const double xn_o = lane_xor1(xn), t0_o = lane_xor1(t0), t1_o = lane_xor1(t1), t2_o = lane_xor1(t2),
+                         d10 = lane_xor1(dlo), d11 = lane_xor1(dcc);
             double ll = INFINITY;
             int64_t ix = INT64_MAX;
             if (live && !odd) {
