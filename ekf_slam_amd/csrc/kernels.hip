@@ -618,8 +618,8 @@ constexpr int kFuseElems = kFuseMaxRows * kFuseMaxRows / 256;     // elements of
 // per-workgroup winners of this observation's association (dl.parts_in), reduced redundantly by every wavefront; and the NEXT
 // observation's association (Correspondence.m:49-87: per-landmark phi_k, Mahalanobis + signature cost, thresholded arg-min) is
 // evaluated in the epilogue by the column lanes, from the values this correction has just produced -- x', strip', Prr', the
-// landmark's own 2x2 block patched with the pending pairs and this correction's pair -- with the per-entry functions k_associate
-// uses: one launch per observation instead of two.
+// landmark's own 2x2 block (its live F64 copy, to which the lanes have just applied this correction's pair) -- with the per-entry
+// functions k_associate uses: one launch per observation instead of two.
 template <typename TS, bool kSharded, bool kPredict, bool kFused = false, bool kDev = false>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa,
                                                          typename DevLoopParam<kDev>::type dl) {
