@@ -196,7 +196,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     assert traces[1] <= traces[0] * (1 + 1e-7)              # a correction never increases trace(P) (to float rounding of the tiles)
     assert e32.N == e64.N == cap
     passes = steps / batch + 2                              # + the two digests above
-    tol = 6e-8                                              # one float rounding of a largest entry; DESIGN.md section 5 states 2e-9 + 6e-12 K for the max-norm
+    tol = 2e-8                                              # measured 3e-9; DESIGN.md section 5 states 2e-9 + 6e-12 K for the max-norm over ALL entries
     n = 3 + 2 * cap
     x32, x64 = e32.get_x(), e64.get_x()
     assert np.isfinite(x32).all()
