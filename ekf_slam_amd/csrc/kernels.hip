@@ -68,20 +68,6 @@ __device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
 
 __device__ __forceinline__ int ring_slot(int pstart, int i, int pcap) { const int s = pstart + i; return s >= pcap ? s - pcap : s; }
 
-// live value of canonical element (r >= c enforced here) = base - sum over pending pairs, in slot order
-template <typename TS>
-__device__ __forceinline__ double pmm_live(const TS *__restrict__ tiles, const DevState &st, int pstart, int npend, int64_t r, int64_t c) {
-    if (r < c) { const int64_t t = r; r = c; c = t; }
-    double v = pmm_low<TS>(tiles, st.tm, r, c);
-    for (int i = 0; i < npend; ++i) {
-        const int64_t so = (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
-        const double2 k = reinterpret_cast<const double2 *>(st.Kp + so)[r];
-        const double2 g = reinterpret_cast<const double2 *>(st.Gp + so)[c];
-        v = rank2_apply(v, k, g);
-    }
-    return v;
-}
-
 // full-state element P(r,c), r,c in [0, 3+n_mm)
 template <typename TS>
 __device__ __forceinline__ double p_at(const DevState &st, int cur, int64_t r, int64_t c) {
