@@ -754,9 +754,6 @@ int32_t collect_decision(ekf_handle *h, AssocHostPartial *set, int32_t nblk, int
 int32_t launch_assoc(ekf_handle *h, const double z[3], const double R[4], AssocHostPartial *host_set_dev, int32_t seq,
                      bool exchange = false, bool want_costs = false, bool fold_predict = false) {
     REQUIRE(h, h->N >= 1, EKF_ERR_STATE, "associate: the state holds no landmark (Correspondence.m:29)");
-    REQUIRE(h, exchange || h->cfg.world == 1 || h->cfg.w_pos == 0.0, EKF_ERR_STATE,
-            "associate: with w_pos != 0 a sharded handle needs the candidates of the other shards (ekf_comm_init, or "
-            "ekf_associate_begin / your all-gather / ekf_associate_finish)");
     if (!fold_predict) {
         const int32_t rcp = materialize_predict(h);
         if (rcp) return rcp;
@@ -834,18 +831,9 @@ int32_t verify_speculated(ekf_handle *h) {
 
 int32_t do_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
                      double *pos_cost, double *sig_cost) {
-    if (h->sharded && (h->cfg.w_pos != 0.0 || pos_cost)) {
-        // the position cost needs every landmark's diagonal block, and those are dealt over the shards: one small all-gather
-        // (SURVEY.md 8e).  The signature-only decision (the reference's, Correspondence.m:75) needs none.
-        REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
-                "associate: position costs on a sharded handle need an exchange -- call ekf_comm_init, or drive "
-                "ekf_associate_begin / your own all-gather / ekf_associate_finish");
-        int32_t rc = assoc_begin(h, z, R, pos_cost != nullptr);
-        if (rc) return rc;
-        rc = exchange_rccl(h);
-        if (rc) { h->pending = false; return rc; }
-        return assoc_finish(h, is_new, idx, pos_cost, sig_cost);
-    }
+    // Sharded handles need NO exchange here (they did until round 3): the position cost needs each landmark's own 2x2 block,
+    // and those blocks are replicated, live, on every shard (DevState::diag) -- every shard evaluates every landmark and takes the same
+    // decision from the same bits.  (ekf_associate_begin / _finish remain for hosts that were written around the exchange.)
     const int32_t seq = next_assoc_seq(h);
     const int64_t N = h->N;
     AssocHostPartial *set = h->h_parts + (int64_t)ekf_handle::kSpecRing * h->parts_stride;

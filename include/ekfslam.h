@@ -152,13 +152,14 @@ int32_t ekf_correct(ekf_handle *h, const double z[2], const double R[4], int64_t
  * optional N-element outputs (Correspondence.m:69,71), may be NULL. */
 int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32_t *is_new, int64_t *idx,
                       double *pos_cost, double *sig_cost);
-/* On a sharded handle (cfg.world > 1) the signature-only decision (w_pos == 0, the reference's live likelihood) is taken
- * identically by every shard from replicated data.  The position cost needs each landmark's 2x2 diagonal block, and those are
- * dealt over the shards: with w_pos != 0, or when pos_cost is asked for, every shard scores the landmarks whose diagonal block
- * it holds, the candidates {likelihood, index} -- and the position costs, if asked for -- travel in ONE all-gather of
- * 4 (+ N) doubles per shard, and every shard takes the same strict arg-min (lowest likelihood, lowest index on ties: the
- * decision of the unsharded handle bit for bit).  ekf_associate / ekf_measure run begin + ncclAllGather + finish on a handle with
- * ekf_comm_init; ekf_associate_begin / _finish bracket the caller's exchange otherwise (ekf_exchange_info, ekf_exchange_local). */
+/* On a sharded handle (cfg.world > 1) ekf_associate / ekf_measure need NO exchange, whatever w_pos: signatures, x, the robot block and
+ * the strip are replicated, and so are the landmarks' own 2x2 diagonal blocks (live F64 copies that every correction's gather kernel
+ * updates on every shard) -- every shard scores every landmark and takes the same decision, the unsharded handle's bit for bit.
+ * (Until round 3 the diagonal blocks were only in the tiles, dealt over the shards, and a position cost needed ONE all-gather of the shards'
+ * candidates.)  That exchange is still offered for hosts written around it: every shard scores the landmarks whose diagonal TILE it
+ * holds, the candidates {likelihood, index} -- and the position costs, if asked for -- travel in one all-gather of 4 (+ N) doubles per
+ * shard run by the caller between _begin and _finish (ekf_exchange_info, ekf_exchange_local), and every shard takes the same strict
+ * arg-min (lowest likelihood, lowest index on ties). */
 int32_t ekf_associate_begin(ekf_handle *h, const double z[3], const double R[4], int32_t want_costs);
 int32_t ekf_associate_finish(ekf_handle *h, int32_t *is_new, int64_t *idx, double *pos_cost, double *sig_cost);
 

@@ -127,27 +127,30 @@ def test_shard_group_association_with_position_cost(world, tile, batch, oracle_l
     g.close(); one.close()
 
 
-def test_position_cost_on_a_shard_needs_an_exchange():
-    """A lone shard cannot score the landmarks whose diagonal blocks live elsewhere: ekf_associate with w_pos != 0 (or asking
-    for the cost vector) on a sharded handle without a communicator is refused, loudly; the signature-only decision is not."""
-    from ekf_slam_amd import EkfError, _lib as L
+def test_position_cost_on_a_lone_shard_needs_no_exchange():
+    """Until round 3 a shard could only score the landmarks whose diagonal TILE it held, and ekf_associate with w_pos != 0 (or asking for
+    the cost vector) needed an all-gather of candidates.  The landmarks' 2x2 diagonal blocks are now replicated (live F64 copies kept by
+    every correction's gather): a lone shard, no communicator, answers like the unsharded engine -- decision and costs, bit for bit."""
+    from ekf_slam_amd import Engine, EkfError
     from ekf_slam_amd.sharding import ShardGroup
     N = 40
     x, P, s, _, _ = _state(N, 52)
-    g = ShardGroup(2, mode="uc", capacity=N, tile=16)
-    g.set_state(x, P, s)
+    g = ShardGroup(2, mode="uc", capacity=N, tile=16, batch=4)
+    one = Engine(mode="uc", capacity=N, tile=16, batch=4)
+    g.set_state(x, P, s); one.set_state(x, P, s)
     R = np.diag([1.0, 50.0])
-    assert g.shards[1].associate([7.0, 123.0, 5.0], R) == (False, 4)
-    with pytest.raises(EkfError) as ei:
-        g.shards[1].associate([7.0, 123.0, 5.0], R, want_costs=True)
-    assert ei.value.status == L.EKF_ERR_STATE and "exchange" in str(ei.value)
-    g.set_params(w_pos=1.0)
-    with pytest.raises(EkfError) as ei:
-        g.shards[0].associate([7.0, 123.0, 5.0], R)
-    assert ei.value.status == L.EKF_ERR_STATE
+    z = [7.0, 123.0, 5.0]
+    g.correct([6.0, 100.0], R, 3); one.correct([6.0, 100.0], R, 3)       # a pending pair: the live blocks carry it already
+    assert g.shards[1].associate(z, R) == one.associate(z, R) == (False, 4)
+    for sh in g.shards:
+        a, b = sh.associate(z, R, want_costs=True), one.associate(z, R, want_costs=True)
+        assert a[:2] == b[:2]
+        np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
+    g.set_params(w_pos=1.0); one.set_params(w_pos=1.0)
+    assert g.shards[0].associate(z, R) == g.shards[1].associate(z, R) == one.associate(z, R)
     with pytest.raises(EkfError):                              # finish without begin
         g.shards[0].associate_finish()
-    g.close()
+    g.close(); one.close()
 
 
 _CHILD = r"""
