@@ -1619,8 +1619,8 @@ int32_t ekf_get_P_diag_blocks(ekf_handle *h, double *out) {
     if (!h || !out) return fail(h, EKF_ERR_INVALID_ARG, "get_P_diag_blocks: null argument");
     int32_t rc = enter(h);
     if (rc) return rc;
-    rc = flush_pending(h);
-    if (rc) return rc;
+    // no pass over P: what plot() reads (EKF_SLAM.m:180,205) is the robot block and the landmarks' own 2x2 blocks, and both are live
+    // (DevState::prr, DevState::diag carry every correction so far, pending or not)
     const size_t bytes = (size_t)(4 * (h->N + 1)) * 8;
     double *d = nullptr;
     HIPCHK(h, hipMalloc((void **)&d, bytes));

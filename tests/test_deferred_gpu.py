@@ -316,3 +316,41 @@ def test_small_map_fused_downdate_equals_the_two_launch_form_bitwise(tile, oracl
     np.testing.assert_array_equal(imm.get_x(), dfr.get_x())
     np.testing.assert_array_equal(imm.get_P(), dfr.get_P())
     assert rel_err(imm.get_P(), ref.P) < REL and rel_err(imm.get_x(), ref.x) < REL
+
+
+@pytest.mark.parametrize("storage,tile", [("f64", 64), ("f32", 128)])
+def test_diag_blocks_are_live_without_a_pass(storage, tile):
+    """What plot() reads (EKF_SLAM.m:180,205: P(1:2,1:2) and every landmark's 2x2 diagonal block) comes from the live copies every
+    correction updates at once: ekf_get_P_diag_blocks answers with pending pairs still pending (no pass over P), and -- with F64
+    tiles -- returns exactly what the flushed matrix holds."""
+    from ekf_slam_amd import Engine
+    N = 90
+    x, P, s = _state(N, 21)
+    e = Engine(capacity=N + 2, tile=tile, storage=storage, batch=16)
+    e.set_state(x, P, s)
+    rng = np.random.default_rng(8)
+    for step in range(11):
+        e.predict([0.1, 2.0])
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        e.correct(z, np.diag([z[0] * .01, z[1] * 5.0]), int(rng.integers(0, N)))
+        if step == 5:
+            e.append([0.1, 2.0], np.diag([.2, 40.0]), [3.0, -4.0], N + 1)
+    assert e.pending() == 11
+    blocks = e.get_P_diag_blocks()
+    assert e.pending() == 11                                   # ... and they still are
+    Pf = e.get_P()                                             # this one flushes
+    assert e.pending() == 0
+    want = [Pf[0:2, 0:2]] + [Pf[3 + 2 * k:5 + 2 * k, 3 + 2 * k:5 + 2 * k] for k in range(e.N)]
+    for got, w in zip(blocks, want):
+        np.testing.assert_array_equal(got, w)
+    if storage == "f64":                                       # F64 tiles: the live copies ARE the tile entries the pass writes, bit for bit
+        ref = Engine(capacity=N + 2, tile=tile, storage=storage, batch=1)
+        ref.set_state(x, P, s)
+        rng = np.random.default_rng(8)
+        for step in range(11):
+            ref.predict([0.1, 2.0])
+            z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+            ref.correct(z, np.diag([z[0] * .01, z[1] * 5.0]), int(rng.integers(0, N)))
+            if step == 5:
+                ref.append([0.1, 2.0], np.diag([.2, 40.0]), [3.0, -4.0], N + 1)
+        np.testing.assert_array_equal(ref.get_P(), Pf)
