@@ -16,6 +16,7 @@ EKF_ERR_INDEX, EKF_ERR_LOOKUP, EKF_ERR_STATE, EKF_ERR_COMM = 5, 6, 7, 8
 EKF_MODE_KNOWN, EKF_MODE_UC = 0, 1
 EKF_COMM_ID_BYTES = 128
 EKF_STORE_F64, EKF_STORE_F32 = 0, 1
+EKF_ARITH_F64, EKF_ARITH_F32 = 0, 1
 (EKF_KERNEL_DOWNDATE, EKF_KERNEL_GATHER, EKF_KERNEL_PREDICT, EKF_KERNEL_ASSOCIATE, EKF_KERNEL_APPEND,
  EKF_KERNEL_COUNT) = range(6)
 
@@ -31,7 +32,7 @@ class EkfConfig(ctypes.Structure):
     _fields_ = [("C", _d), ("Rc", _d * 2), ("s_cost", _d), ("s_thresh", _d), ("w_pos", _d),
                 ("capacity_landmarks", _i64), ("mode", _i32), ("storage", _i32), ("device", _i32),
                 ("tile", _i32), ("rank", _i32), ("world", _i32), ("batch", _i32), ("async_flush", _i32), ("device_assoc", _i32),
-                ("pass_direction", _i32), ("force_sharded", _i32), ("reserved", _i32 * 3)]
+                ("pass_direction", _i32), ("force_sharded", _i32), ("pass_arith", _i32), ("reserved", _i32 * 2)]
 
 
 # name -> (restype, argtypes); every symbol of include/ekfslam.h

@@ -356,7 +356,7 @@ int32_t flush_pending(ekf_handle *h) {
         }
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
         HIPCHK(h, launch_downdate(h->st, h->st.tiles, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart, h->npend,
-                                  h->storage, h->grid_cap, h->stream, h->dd_kernel, nx.j >= 0 ? &nx : nullptr, &extracted));
+                                  h->storage, h->grid_cap, h->stream, h->dd_kernel, nx.j >= 0 ? &nx : nullptr, &extracted, h->cfg.pass_arith));
         h->dd_pairs = h->npend;
     }
     h->npend = 0;
@@ -396,7 +396,7 @@ int32_t batch_complete(ekf_handle *h) {
         }
         next_pass_direction(h);
         HIPCHK(h, launch_downdate(h->st, h->tilebuf[h->base ^ 1], h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart,
-                                  h->npend, h->storage, h->grid_cap, h->flush_stream, h->dd_kernel));
+                                  h->npend, h->storage, h->grid_cap, h->flush_stream, h->dd_kernel, nullptr, nullptr, h->cfg.pass_arith));
         h->dd_pairs = h->npend;
         if (stop) HIPCHK(h, hipEventRecord(stop, h->flush_stream));
     }
@@ -957,6 +957,8 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
     if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;
     if (cfg->batch < 0 || cfg->batch > 64) return EKF_ERR_INVALID_ARG;
+    if (cfg->pass_arith != EKF_ARITH_F64 && !(cfg->pass_arith == EKF_ARITH_F32 && cfg->storage == EKF_STORE_F32 && T == 256))
+        return EKF_ERR_INVALID_ARG;                   // the f32-arithmetic pass exists for float tiles of edge 256 only
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return EKF_ERR_NO_DEVICE;

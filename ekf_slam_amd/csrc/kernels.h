@@ -171,7 +171,7 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 struct NextRow { int64_t j; double *send; };
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx = nullptr,
-                           bool *extracted = nullptr);
+                           bool *extracted = nullptr, int arith = 0);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries; ticket: a
 // device int, zero between launches (the last workgroup to finish reduces the partials and resets it: one launch, no
 // finishing kernel); decision: device copy.  host_partials != nullptr (mapped host memory, one entry per workgroup): NO cross-workgroup

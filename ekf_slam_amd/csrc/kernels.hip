@@ -1978,6 +1978,130 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
     }
 }
 
+// "F32 mixed precision with F64 innovation solve" (BASELINE.json configs[4]; cfg.pass_arith = EKF_ARITH_F32): the same pass over float tiles
+// with the rank-2m product ON THE F32 MATRIX PIPE -- v_mfma_f32_16x16x4_f32, twice the f64 instruction's rate on gfx950 (256 against 128
+// flop/clk/CU), a float accumulator per element (the tile's own 16 bytes per lane and row: no widening, half the registers).  -K and G are
+// rounded to float when they are staged; everything that DECIDES anything -- innovation, S, its inverse, K, the state, the robot block, the
+// strip, the landmarks' diagonal blocks (DevState::diag) -- stays in F64 in the gather kernel.  What changes against the F64-arithmetic pass is
+// the rounding of the off-diagonal landmark entries: one float rounding per rank-1 term instead of one per pass (tolerance: DESIGN.md 5).
+// Geometry as k_flush_mfma's (a workgroup = 64 rows x 128 columns, a wavefront 16 rows x 128 columns = 8 accumulator blocks); the f32
+// instruction's result layout differs from the f64 one's: lane (lr, lc) register r is row 4 lr + r (f64: lr + 4 r) of column block lc.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+template <int T, int kChunk, int kRG, int kWpe>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
+void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
+                    const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
+                    int npairs, TileMap tm) {
+    // kRG: 16-row groups per wavefront -- a workgroup owns 64 kRG rows x 128 columns (kRG = 2: twice the bytes in flight per workgroup and
+    // one read of G from LDS for 16 instead of 8 MFMAs).  Production: kChunk = 4, kRG = 2, four wavefronts per SIMD (profiles/round3_tuning.md 36).
+    constexpr int kRows = 64 * kRG, kCols = 128, kKPad = kRows + 16;
+    constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
+    static_assert(T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 kRG rows x 128 columns");
+    static_assert(kChunk % 2 == 0 && (kChunk * kCols) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
+    __shared__ __attribute__((aligned(16))) float Gs[2 * kChunk][kCols];
+    __shared__ float Ks[2 * kChunk][kKPad];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane >> 4, lc = lane & 15;
+    const int64_t nitems = 8 * nwork * kSubsPerTile;
+    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int64_t vi = tm.reverse ? nwork * kSubsPerTile - 1 - (it >> 3) : (it >> 3);
+        const int64_t w = vi / kSubsPerTile;
+        const int sub = (int)(vi - w * kSubsPerTile);
+        const int2 ij = work[(it & 7) * nwork + w];
+        if (ij.x < 0) continue;
+        const int slab = sub / kColParts, cpart = sub - slab * kColParts;
+        const int row0 = slab * kRows + wave * 16;                    // row group rg: + 64 rg
+        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + 4 * lr) * T + cpart * kCols + 4 * lc;
+        const float *__restrict__ tp = tiles + toff;
+        float *__restrict__ td = dst + toff;
+        f4_t acc[kRG][2][4];                                          // [row group][16-byte group bp][column e in it][row r -> row0 + 64 rg + 4 lr + r]
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[rg][bp][e][r] = v[e];
+                }
+        const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
+        const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
+        constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
+        double2 tg[kPerG], tk[kPerK];
+        auto fetch = [&](int c0, int cn) {
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, col = e & (kCols - 1);
+                const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;
+                tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
+            }
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, row = e & (kRows - 1);
+                const int i = (e / kRows) < cn ? (e / kRows) : cn - 1;
+                tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
+            }
+        };
+        auto stage = [&](int cn) {                           // the fetched chunk, rounded to float, de-interleaved to [k][col] / [k][row]
+#pragma unroll
+            for (int q = 0; q < kPerG; ++q) {
+                const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
+                if (i < cn) { Gs[2 * i][col] = (float)tg[q].x; Gs[2 * i + 1][col] = (float)tg[q].y; }
+                else if (i == cn) { Gs[2 * i][col] = 0.0f; Gs[2 * i + 1][col] = 0.0f; }       // pad of an odd count
+            }
+#pragma unroll
+            for (int q = 0; q < kPerK; ++q) {
+                const int e = tid + q * kBlock, i = e / kRows, row = e & (kRows - 1);
+                if (i < cn) { Ks[2 * i][row] = -(float)tk[q].x; Ks[2 * i + 1][row] = -(float)tk[q].y; }
+                else if (i == cn) { Ks[2 * i][row] = -0.0f; Ks[2 * i + 1][row] = -0.0f; }
+            }
+        };
+        auto apply = [&](int cn) {
+            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
+#pragma unroll 2
+            for (int ks = 0; ks < ksteps; ++ks) {
+                float a[kRG];
+#pragma unroll
+                for (int rg = 0; rg < kRG; ++rg) a[rg] = Ks[4 * ks + lr][64 * rg + wave * 16 + lc];
+                f4_t b[2];
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp) b[bp] = *reinterpret_cast<const f4_t *>(&Gs[4 * ks + lr][64 * bp + 4 * lc]);
+#pragma unroll
+                for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+                    for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[rg][bp][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg], b[bp][e], acc[rg][bp][e], 0, 0, 0);
+            }
+        };
+        auto count = [&](int c0) { return npairs - c0 < kChunk ? npairs - c0 : kChunk; };
+        fetch(0, count(0));
+        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+            __syncthreads();                                          // everyone is done with the previous chunk
+            stage(count(c0));
+            __syncthreads();
+            if (c0 + kChunk < npairs) fetch(c0 + kChunk, count(c0 + kChunk));
+            apply(count(c0));
+        }
+#pragma unroll
+        for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[rg][bp][e][r];
+                    __builtin_nontemporal_store(o, reinterpret_cast<f4_t *>(td + (int64_t)(64 * rg + r) * T + 64 * bp));
+                }
+    }
+}
+
 // what was launched, for the measurement hooks (ekf_downdate_kernel_name): "k_xxx<double,128,4,false>"
 static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, int xcd) {
     if (!out) return;
@@ -1988,7 +2112,7 @@ static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, 
 // the MFMA flush for the (storage type, tile edge) pairs it exists for; false: not applicable, use the VALU kernels
 template <typename TS, int T>
 static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_xcd, int64_t xcd_len, int pstart, int npairs,
-                              int grid_cap, hipStream_t s, char *kname) {
+                              int grid_cap, hipStream_t s, char *kname, int arith) {
     constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
     if constexpr (kHave) {
         static const bool use_mfma = ekf_tune_int("EKF_FLUSH_MFMA", 1) != 0;
@@ -2000,6 +2124,28 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         constexpr int kSubs = (T / 64) * (T / 128);
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
+        if constexpr (sizeof(TS) == 4) {
+            if (arith == 1) {                                         // cfg.pass_arith = EKF_ARITH_F32: the f32 matrix pipe
+#define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
+                                  hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \
+                                           (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                                  if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d>", T, CH, RG, WPE); } while (0)
+#ifdef EKF_TUNING
+                const int v = 100 * ekf_tune_int("EKF_MFMA32_RG", 2) + 10 * ekf_tune_int("EKF_MFMA32_CHUNK", 4) + ekf_tune_int("EKF_MFMA32_WPE", 4);
+                switch (v) {
+                    case 144: EKF_M32(4, 1, 4); return true;
+                    case 146: EKF_M32(4, 1, 6); return true;
+                    case 184: EKF_M32(8, 1, 4); return true;
+                    case 243: EKF_M32(4, 2, 3); return true;
+                    case 283: EKF_M32(8, 2, 3); return true;
+                    default: break;
+                }
+#endif
+                EKF_M32(4, 2, 4);
+#undef EKF_M32
+                return true;
+            }
+        }
         if (npairs <= chunk_switch)
             hipLaunchKernelGGL((k_flush_mfma<TS, T, 4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
                                work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
@@ -2016,10 +2162,10 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                      int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname,
-                                     const NextRow *nx, bool *extracted) {
+                                     const NextRow *nx, bool *extracted, int arith) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = ekf_tune_int("EKF_FLUSH_XCD", 1) != 0;
-    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname)) return hipGetLastError();
+    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, arith)) return hipGetLastError();
     if constexpr (kLanes == 64 || kLanes == 32) {
         if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
             int64_t grid = 8 * xcd_len * (T / kSlab);
@@ -2061,10 +2207,10 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
 template <typename TS>
 static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s, char *kname,
-                                    const NextRow *nx, bool *extracted) {
+                                    const NextRow *nx, bool *extracted, int arith) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, nx, extracted)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, nx, extracted, arith)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -2091,13 +2237,13 @@ static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *
 
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx,
-                           bool *extracted) {
+                           bool *extracted, int arith) {
     if (extracted) *extracted = false;
     static const int slab1 = ekf_tune_int("EKF_DOWNDATE_SLAB", 0);
     static const int slabm = ekf_tune_int("EKF_DOWNDATE_SLAB_BATCH", 0);
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted)
-                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted);
+    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith)
+                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

@@ -45,6 +45,8 @@ enum { EKF_MODE_KNOWN = 0,   /* EKF_SLAM.m    : known correspondence   */
 
 enum { EKF_STORE_F64 = 0,    /* P tiles stored as double                               */
        EKF_STORE_F32 = 1 };  /* P tiles stored as float, every solve still in double   */
+enum { EKF_ARITH_F64 = 0,    /* the pass over P forms P - sum K_i G_i in double (one rounding per pass when the tiles are float) */
+       EKF_ARITH_F32 = 1 };  /* F32 tiles with tile = 256 only: the pass runs on the f32 matrix pipe (cfg.pass_arith below)      */
 
 /* Hard-coded property defaults of the reference collected in one struct
  * (EKF_SLAM.m:12-16, EKF_SLAM_UC.m:13,16). */
@@ -66,14 +68,16 @@ typedef struct ekf_config {
     int32_t world;               /* number of shards P is split over; 0 or 1 = unsharded            */
     int32_t batch;               /* deferred downdate: up to `batch` corrections are kept as pending rank-2
                                     pairs (the rows later corrections need are patched on the fly) and applied
-                                    to P in ONE pass; results are bit-identical to batch = 1.  0 or 1 = every
+                                    to P in ONE pass; with F64 tiles results are bit-identical to batch = 1 (F32 tiles round once
+                                    per pass, so the batch moves the roundings: equal within the F32 tolerance).  0 or 1 = every
                                     correction rewrites P immediately (EKF_SLAM.m:145 as written); max 64  */
     int32_t async_flush;         /* run each pass over P on a second stream, from the current tile store into a
                                     second one (2x tile memory), while the next corrections go on reading the current
                                     store plus all pending pairs; stores swap at the next batch boundary.  With
                                     batch = 1 that is the as-written update-step software-pipelined: the pass of step i
                                     beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
-                                    async_flush = 0.  The second stream is confined to a CU mask that leaves 32 CUs
+                                    async_flush = 0 with F64 tiles (with F32 tiles the corrections beside a pass read its pairs
+                                    unrounded where the synchronous engine reads the rounded tiles: equal within the F32 tolerance).  The second stream is confined to a CU mask that leaves 32 CUs
                                     to the corrections.  Pays when a batch's corrections take
                                     about as long as its pass; with batch = 1 it has measured slower than the in-place
                                     pass at every map size on one GPU (two stores defeat the cache). */
@@ -104,7 +108,14 @@ typedef struct ekf_config {
                                     on-die), forwards otherwise; 1 = always forwards; 2 = always alternate.  Same bits. */
     int32_t force_sharded;       /* 1: run the sharded code path (row-panel extraction, exchange, sharded gather) although
                                     world == 1 -- how that path is exercised and timed on a single GPU */
-    int32_t reserved[3];
+    int32_t pass_arith;          /* EKF_ARITH_*: arithmetic of the pass over P.  EKF_ARITH_F32 ("F32 mixed precision with F64 innovation
+                                    solve", BASELINE.json configs[4]) needs storage = EKF_STORE_F32 and tile = 256 (EKF_ERR_INVALID_ARG
+                                    otherwise): the pending pairs' K and G are rounded to float and the rank-2m product is accumulated in
+                                    float on the f32 matrix pipe (twice the f64 pipe's rate: batches of 32-64 stay HBM-bound).  The
+                                    innovation, S, K, x, the robot block, the strip and the landmarks' 2x2 diagonal blocks are F64 as
+                                    always.  Off-diagonal landmark entries then see one float rounding per rank-1 term instead of one
+                                    per pass; measured against the F64 engine: DESIGN.md section 5. */
+    int32_t reserved[2];
 } ekf_config;
 
 typedef struct ekf_handle ekf_handle;

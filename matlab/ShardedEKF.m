@@ -9,13 +9,17 @@ classdef ShardedEKF < handle
         hnd;                  % uint64 column, one handle per shard
     end
     methods
-        function g = ShardedEKF(mode, capacity, devices, tile, batch)
+        function g = ShardedEKF(mode, capacity, devices, tile, batch, storage, pass_arith)
+            % storage: 0 = F64 tiles (default), 1 = F32 tiles with every solve in F64; pass_arith: 1 = the pass over F32 tiles in F32
+            % arithmetic on the matrix pipe ("F32 mixed precision with F64 innovation solve"; include/ekfslam.h, cfg.pass_arith)
             if nargin < 4, tile = 0; end
             if nargin < 5, batch = 1; end
+            if nargin < 6, storage = 0; end
+            if nargin < 7, pass_arith = 0; end
             w = numel(devices);
             g.hnd = zeros(w, 1, 'uint64');
             for r = 1:w
-                g.hnd(r) = ekfslam_mex('create', mode, capacity, tile, batch, devices(r), r - 1, w);
+                g.hnd(r) = ekfslam_mex('create', mode, capacity, tile, batch, devices(r), r - 1, w, storage, pass_arith);
             end
         end
         function delete(g)

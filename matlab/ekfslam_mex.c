@@ -45,7 +45,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgIdAndTxt("ekfslam:usage", "command string expected");
 
     /* ---- commands without a handle ---- */
-    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile [, batch [, device, rank, world]]]) */
+    if (!strcmp(cmd, "create")) {                 /* h = ekfslam_mex('create', mode, capacity [, tile [, batch [, device, rank, world [, storage [, pass_arith]]]]]) */
         ekf_config cfg;
         ekf_handle *h = NULL;
         need(nrhs, 3, cmd);
@@ -59,6 +59,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             cfg.rank = (int32_t)mxGetScalar(prhs[6]);
             cfg.world = (int32_t)mxGetScalar(prhs[7]);
         }
+        if (nrhs > 8) cfg.storage = (int32_t)mxGetScalar(prhs[8]);    /* EKF_STORE_*: 1 = float tiles (BASELINE configs[4]) */
+        if (nrhs > 9) cfg.pass_arith = (int32_t)mxGetScalar(prhs[9]); /* EKF_ARITH_*: 1 = the pass over float tiles in F32 arithmetic */
         int32_t rc = ekf_create(&cfg, &h);
         if (rc != EKF_OK) {
             char msg[256];

@@ -4,7 +4,7 @@
 Starts from N0 bulk-loaded landmarks (P = D + U U'), capacity N0 + steps; every step = predict + append of one new
 landmark + one correction on a cycling landmark (EKF_SLAM.m:40-51, :67-98, :124-145).  Prints one JSON line.
 
-    python scripts/bench_config5.py [--landmarks 40000] [--steps 512] [--batch 32]
+    python scripts/bench_config5.py [--landmarks 40000] [--steps 512] [--batch 12] [--storage f32|f32_mixed|f64]
 """
 import argparse
 import json
@@ -24,8 +24,8 @@ def main():
     ap.add_argument("--landmarks", type=int, default=40000)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--storage", default="f32")
+    ap.add_argument("--batch", type=int, default=12, help="12 is the usable point of the F64-arithmetic pass on float tiles; 32-64 with --storage f32_mixed")
+    ap.add_argument("--storage", default="f32", help="f32: float tiles, F64 arithmetic; f32_mixed: float tiles, the pass in F32 arithmetic (cfg.pass_arith); f64")
     args = ap.parse_args()
     from ekf_slam_amd import Engine, _lib as L
     from ekf_slam_amd.world import World
@@ -51,34 +51,43 @@ def main():
         (_, r, b), = w.observe([k])
         steps.append((u, np.array([r, b]), np.diag([r * Rc[0], b * Rc[1]]), k, w.landmarks[N0 + t]))
 
-    def run(chunk):
-        for (u, z, R, k, pos) in chunk:
-            e.predict(u)
-            e.append(u, R, pos, e_N[0] + 1)
+    # the steps marshalled once (Engine.marshal_steps) and driven through the C ABI's entry points directly, as bench.py does: the timed
+    # loop measures the library, not numpy conversions of the Python front-end (~20 us per call, three calls per step)
+    import ctypes
+    marsh = e.marshal_steps([(u, z, R, k) for (u, z, R, k, _) in steps])
+    POS = np.ascontiguousarray([p for (_, _, _, _, p) in steps], dtype=np.float64)
+    f_pred, f_corr = e._raw[0], e._raw[1]
+    f_app = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double)(("ekf_append", e.lib))
+
+    def run(i0, i1):
+        for i in range(i0, i1):
+            rc = f_pred(e.h, marsh["u"] + 16 * i) or f_app(e.h, marsh["u"] + 16 * i, marsh["r"] + 32 * i, POS.ctypes.data + 16 * i, float(e_N[0] + 1))
             e_N[0] += 1
-            e.correct(z, R, k)
+            rc = rc or f_corr(e.h, marsh["z"] + 16 * i, marsh["r"] + 32 * i, marsh["k"][i])
+            if rc:
+                e._check(rc)
         e.flush()
 
     e_N = [N0]
-    run(steps[:args.warmup])
+    run(0, args.warmup)
     e.sync()
     e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=args.steps + 8)
     n_start = 3 + 2 * e_N[0]
     t0 = time.perf_counter()
-    run(steps[args.warmup:])
+    run(args.warmup, total)
     e.sync()
     dt = time.perf_counter() - t0
     launches, ms = e.timing_read(L.EKF_KERNEL_DOWNDATE)
     kernel, kpairs = e.downdate_kernel_name()
     n_end = 3 + 2 * e_N[0]
-    w_bytes = 4 if args.storage == "f32" else 8
+    w_bytes = 4 if args.storage.startswith("f32") else 8
     n_mid = (n_start + n_end) / 2
     b_alg = w_bytes * n_mid * (n_mid + 1)
     avg_ms = ms / max(launches, 1)
     finite = bool(np.isfinite(e.get_x()).all())
     out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I−KH)P vs roofline",
            "value": args.steps / dt, "unit": "update-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s tiles" % args.storage, "data": "synthetic",
+           "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s" % {"f32": "f32 tiles, f64 pass arithmetic", "f32_mixed": "f32 tiles, f32 pass arithmetic (matrix pipe)", "f64": "f64 tiles"}[args.storage], "data": "synthetic",
            "config": {"workload": "configs[4] shape on 1 GPU: %d -> %d landmarks, %s tile storage, F64 solve, step = predict + "
                                   "append + 1 correction (streaming landmark append)" % (N0 + args.warmup, e_N[0], args.storage),
                       "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,

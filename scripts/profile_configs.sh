@@ -19,6 +19,12 @@ python scripts/bench_config5.py --batch 12 --steps 384 > $OUT/config5_40k_b12.js
 python scripts/bench_config5.py --batch 32 --steps 512 > $OUT/config5_40k_b32.json 2>/dev/null
 python scripts/bench_config5.py --landmarks 49400 --batch 12 --steps 384 > $OUT/config5_50k_b12.json 2>/dev/null
 python scripts/bench_config5.py --landmarks 49400 --batch 1 --steps 64 --warmup 16 > $OUT/config5_50k_b1.json 2>/dev/null
+# ... and the same shape with the pass in F32 arithmetic on the matrix pipe (cfg.pass_arith = EKF_ARITH_F32: "F32 mixed precision with F64 innovation solve")
+python scripts/bench_config5.py --storage f32_mixed --batch 1 --steps 96 --warmup 16 > $OUT/config5_40k_mixed_b1.json 2>/dev/null
+python scripts/bench_config5.py --storage f32_mixed --batch 12 --steps 384 > $OUT/config5_40k_mixed_b12.json 2>/dev/null
+python scripts/bench_config5.py --storage f32_mixed --batch 32 --steps 512 > $OUT/config5_40k_mixed_b32.json 2>/dev/null
+python scripts/bench_config5.py --storage f32_mixed --batch 64 --steps 512 > $OUT/config5_40k_mixed_b64.json 2>/dev/null
+python scripts/bench_config5.py --storage f32_mixed --landmarks 49400 --batch 32 --steps 512 > $OUT/config5_50k_mixed_b32.json 2>/dev/null
 python scripts/bench_cpu_restatements.py > $OUT/cpu_baselines.json 2>$OUT/cpu_baselines.err
 for f in $OUT/config*.json; do python -c "
 import json,sys

@@ -24,6 +24,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     h->cap = cfg->capacity_landmarks; h->N = 0;
     *out = h;
     h->rank = cfg->rank; h->world = cfg->world;
+    if (cfg->storage || cfg->pass_arith) LOG("ekf_create storage=%d pass_arith=%d", cfg->storage, cfg->pass_arith);
     if (cfg->world > 1) LOG("ekf_create mode=%d cap=%lld tile=%d batch=%d device=%d rank=%d world=%d", cfg->mode,
                             (long long)cfg->capacity_landmarks, cfg->tile, cfg->batch, cfg->device, cfg->rank, cfg->world);
     else

@@ -105,6 +105,8 @@ int main(void) {
     call(0, 2, S("exchange_local"), mock_double(2, 1, u));                            /* not a handle vector */
     call(0, 2, S("exchange_local"), mock_uint64_vec(2, hbad));                        /* a null handle inside */
     call(0, 2, S("exchange_local"), empty);
+    call(1, 10, S("create"), D1(0), D1(64), D1(256), D1(32), D1(0), D1(0), D1(1), D1(1), D1(1));   /* float tiles, F32-arithmetic pass */
+    call(0, 2, S("destroy"), out[0]);
     call(1, 6, S("create"), D1(1), D1(32), D1(0), D1(1), D1(0));                      /* device without rank / world */
     call(0, 2, S("destroy"), g1);
     call(0, 2, S("destroy"), g0);

@@ -32,16 +32,21 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 
-def bound_P(k):
-    return 2e-9 + 6e-12 * k
+def bound_P(k, storage="f32"):
+    return BOUNDS[storage][0] + BOUNDS[storage][1] * k
 
 
-def bound_x(k):
-    return 1e-9 + 2e-12 * k
+def bound_x(k, storage="f32"):
+    return BOUNDS[storage][2] + BOUNDS[storage][3] * k
 
 
-@pytest.mark.parametrize("batch", [1, 12])
-def test_f32_tiles_drift_over_two_thousand_update_steps(batch):
+# (P: offset, per update-step; x: offset, per update-step).  "f32_mixed" = cfg.pass_arith = EKF_ARITH_F32: the pass over P on the f32
+# matrix pipe, K and G rounded to float, one float rounding per rank-1 term (module docstring, last paragraph)
+BOUNDS = {"f32": (2e-9, 6e-12, 1e-9, 2e-12), "f32_mixed": (2e-9, 6e-12, 1e-9, 2e-12)}
+
+
+@pytest.mark.parametrize("storage,batch", [("f32", 1), ("f32", 12), ("f32_mixed", 1), ("f32_mixed", 32)])
+def test_f32_tiles_drift_over_two_thousand_update_steps(storage, batch):
     import bench
     from ekf_slam_amd import Engine
     from ekf_slam_amd.world import World
@@ -54,7 +59,7 @@ def test_f32_tiles_drift_over_two_thousand_update_steps(batch):
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
     e64 = Engine(mode="known", capacity=cap, storage="f64", batch=batch)
-    e32 = Engine(mode="known", capacity=cap, storage="f32", batch=batch)
+    e32 = Engine(mode="known", capacity=cap, storage=storage, batch=batch)
     for e in (e64, e32):
         e.load_lowrank_state(x, s, d, U)
     Rc = [.01, 5.0]
@@ -74,15 +79,15 @@ def test_f32_tiles_drift_over_two_thousand_update_steps(batch):
             ex, eP = rel_err(e32.get_x(), e64.get_x()), rel_err(e32.get_P(), e64.get_P())      # get_P flushes both
             passes = (t + 1) if batch == 1 else (t + 1) / batch + (t + 1) // EVERY              # + the flush each read forces
             log.append({"update_steps": t + 1, "passes_over_P": passes, "rel_err_x": ex, "rel_err_P": eP,
-                        "bound_x": bound_x(t + 1), "bound_P": bound_P(t + 1)})
+                        "bound_x": bound_x(t + 1, storage), "bound_P": bound_P(t + 1, storage)})
             worst_x, worst_P = max(worst_x, ex), max(worst_P, eP)
     assert e32.N == e64.N == N0 + STEPS // 10
     tr32, tr64 = e32.digest()[0], e64.digest()[0]
-    print("f32 drift, batch %d: %s" % (batch, json.dumps(log)))
+    print("%s drift, batch %d: %s" % (storage, batch, json.dumps(log)))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "f32_drift_batch%d.json" % batch), "w") as fh:
-            json.dump({"landmarks": [N0, e32.N], "batch": batch, "log": log}, fh)
+        with open(os.path.join(out, "%s_drift_batch%d.json" % (storage, batch)), "w") as fh:
+            json.dump({"landmarks": [N0, e32.N], "storage": storage, "batch": batch, "log": log}, fh)
     for rec in log:
         assert rec["rel_err_x"] <= rec["bound_x"] and rec["rel_err_P"] <= rec["bound_P"], rec
     assert abs(tr32 - tr64) / abs(tr64) <= log[-1]["bound_P"]

@@ -154,9 +154,11 @@ def test_ten_thousand_landmarks_eight_shards(oracle_lib):
     g.close(); one.close()
 
 
-def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
+@pytest.mark.parametrize("storage,batch", [("f32", 12), ("f32_mixed", 32)])
+def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles(storage, batch):
     """BASELINE.json configs[4]'s shape on one GPU: 40 000 landmarks bulk-loaded, F32 tile storage / F64 solve, every step =
-    predict + append of one new landmark + one correction (streaming append), deferred batch 12 -- against the F64-tile engine
+    predict + append of one new landmark + one correction (streaming append), deferred batch 12 (the pass in F64 arithmetic) and
+    batch 32 with the pass in F32 arithmetic on the matrix pipe (cfg.pass_arith, "f32_mixed") -- against the F64-tile engine
     on the same inputs (the reference's arithmetic is F64 throughout, EKF_SLAM.m:141-145; the structured CPU oracle would need a
     51 GB matrix and minutes per step at this size, and F64 tiles == oracle is what every other test of this file establishes).
     Checked: x (all of it), the digests of P, the robot rows, sampled 6 x 6 blocks on and off the diagonal incl. the appended
@@ -165,7 +167,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     import json, os
     from ekf_slam_amd import Engine
     from ekf_slam_amd.world import World
-    N0, steps, batch = 40000, 96, 12
+    N0, steps = 40000, 96
     cap = N0 + steps
     w = World(cap, 20260101 + 5)
     rng = np.random.default_rng(77)
@@ -175,7 +177,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
     e64 = Engine(mode="known", capacity=cap, storage="f64", batch=batch)
-    e32 = Engine(mode="known", capacity=cap, storage="f32", batch=batch)
+    e32 = Engine(mode="known", capacity=cap, storage=storage, batch=batch)
     for e in (e64, e32):
         e.load_lowrank_state(x, s, d, U)
     Rc = [.01, 5.0]
@@ -210,13 +212,13 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles():
     blocks = [(e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)) for r0, c0 in corners]
     scale = max(float(np.abs(b64).max()) for _, b64 in blocks)        # max-norm over the samples (they include appended diagonal blocks, the largest entries of P)
     eb = max(float(np.abs(a - b64).max()) for a, b64 in blocks) / scale
-    rec = {"landmarks": [N0, cap], "update_steps": steps, "deferred_batch": batch, "passes_over_P": passes, "tolerance": tol,
+    rec = {"landmarks": [N0, cap], "storage": storage, "update_steps": steps, "deferred_batch": batch, "passes_over_P": passes, "tolerance": tol,
            "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er, "rel_err_sampled_blocks": eb,
            "trace_before_after_last_correction": traces}
-    print("config 5 shape, F32 vs F64 tiles: %s" % json.dumps(rec))
+    print("config 5 shape, %s vs F64 tiles: %s" % (storage, json.dumps(rec)))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
-        with open(os.path.join(out, "config5_f32_vs_f64.json"), "w") as fh:
+        with open(os.path.join(out, "config5_%s_vs_f64.json" % storage), "w") as fh:
             json.dump(rec, fh)
     assert ex <= tol and ed <= tol and er <= tol and eb <= tol, rec
     e64.close(); e32.close()

@@ -116,6 +116,8 @@ def test_gateway_marshalling_under_the_mock(transcript):
     assert "ABI ekf_hint_next rank=1 idx0=6" in t                                  # ekf_hint_next: 1-based -> 0-based once
     assert "ABI ekf_associate_begin rank=0 z=5,50,7 R=0.05,0,0,250 costs=0" in t
     assert any(ln.startswith("MEX associate_finish") and "out0=1x1L[0] out1=1x1[5]" in ln for ln in t)
+    i = t.index("ABI ekf_create storage=1 pass_arith=1")                            # create's 9th / 10th argument: cfg.storage, cfg.pass_arith
+    assert t[i + 1] == "ABI ekf_create mode=0 cap=64 tile=256 batch=32"
     assert any(ln.startswith("MEX create nrhs=6 -> ERROR ekfslam:usage") for ln in t)
     assert any("ERROR ekfslam:usage | 'predict' needs 3 arguments" in ln for ln in t)
     assert any("unknown command 'no_such_command'" in ln for ln in t)
