@@ -2017,17 +2017,19 @@ void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, co
         const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + 4 * lr) * T + cpart * kCols + 4 * lc;
         const float *__restrict__ tp = tiles + toff;
         float *__restrict__ td = dst + toff;
+        // The accumulators start at ZERO and hold only the pass's update -sum_i K_i G_i; the tile value is added ONCE at the end (one float rounding
+        // per entry and pass, as the F64-arithmetic pass has).  Accumulating onto the tile value itself (the first version: tile loaded into the
+        // accumulators) rounds at the ENTRY's ulp after every rank-4 step: on the large entries (cross-covariances of appended landmarks, ~10) every
+        // small decrement was lost -- 7e-7 on sampled blocks, 4e-6 on the digests after configs[4]'s 10 000 update-steps (tests/test_full_size_gpu.py).
+        // The tile is requested after the last chunk, a row group's eight 16-byte pieces at a time (holding it in registers from the start spills
+        // at four wavefronts per SIMD; an early "touch" load + the late one moved the bytes twice: profiles/round3_tuning.md 36).
         f4_t acc[kRG][2][4];                                          // [row group][16-byte group bp][column e in it][row r -> row0 + 64 rg + 4 lr + r]
 #pragma unroll
         for (int rg = 0; rg < kRG; ++rg)
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f4_t v = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[rg][bp][e][r] = v[e];
-                }
+                for (int e = 0; e < 4; ++e) acc[rg][bp][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
         const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
         const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
         constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
@@ -2089,7 +2091,13 @@ void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, co
             apply(count(c0));
         }
 #pragma unroll
-        for (int rg = 0; rg < kRG; ++rg)
+        for (int rg = 0; rg < kRG; ++rg) {
+            f4_t tl[2][4];
+#pragma unroll
+            for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    tl[bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
@@ -2097,8 +2105,10 @@ void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, co
                     f4_t o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[rg][bp][e][r];
+                    o += tl[bp][r];
                     __builtin_nontemporal_store(o, reinterpret_cast<f4_t *>(td + (int64_t)(64 * rg + r) * T + 64 * bp));
                 }
+        }
     }
 }
 
@@ -2131,17 +2141,18 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                                            (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
                                   if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d>", T, CH, RG, WPE); } while (0)
 #ifdef EKF_TUNING
-                const int v = 100 * ekf_tune_int("EKF_MFMA32_RG", 2) + 10 * ekf_tune_int("EKF_MFMA32_CHUNK", 4) + ekf_tune_int("EKF_MFMA32_WPE", 4);
+                const int v = 100 * ekf_tune_int("EKF_MFMA32_RG", 0) + 10 * ekf_tune_int("EKF_MFMA32_CHUNK", 4) + ekf_tune_int("EKF_MFMA32_WPE", 4);
                 switch (v) {
                     case 144: EKF_M32(4, 1, 4); return true;
                     case 146: EKF_M32(4, 1, 6); return true;
                     case 184: EKF_M32(8, 1, 4); return true;
                     case 243: EKF_M32(4, 2, 3); return true;
-                    case 283: EKF_M32(8, 2, 3); return true;
+                    case 244: EKF_M32(4, 2, 4); return true;
                     default: break;
                 }
 #endif
-                EKF_M32(4, 2, 4);
+                // three wavefronts per SIMD (all sixteen tile pieces of a wavefront in flight at the end) for the HBM-bound small counts, four beyond
+                if (npairs <= 4) EKF_M32(4, 2, 3); else EKF_M32(4, 2, 4);
 #undef EKF_M32
                 return true;
             }

@@ -1,12 +1,12 @@
 """GPU: "F32 mixed precision with F64 innovation solve" (BASELINE.json configs[4]) -- cfg.storage = EKF_STORE_F32 with
 cfg.pass_arith = EKF_ARITH_F32: the pass over the float tiles runs on the f32 matrix pipe (k_flush_mfma32: -K and G rounded to float,
 products accumulated in float), while the innovation, S, its inverse, K, x, the robot block, the strip and the landmarks' 2x2 diagonal
-blocks stay F64 (EKF_SLAM.m:124-145 is F64 throughout; this mode trades one float rounding per pass for one per rank-1 term on the
-off-diagonal landmark entries).
+blocks stay F64 (EKF_SLAM.m:124-145 is F64 throughout).  The pass's update -sum K_i G_i is summed in float from zero and added to the float
+tile value once: one rounding at the entry's magnitude per pass, as with the F64-arithmetic pass.
 
 Tolerance, stated here: 1e-6 relative (max-norm) on x and P against the F64 oracle after 40 update-steps from a dense random state
-(measured 1-2e-7 on x, 2-4e-7 on P; the F64-arithmetic pass on the same float tiles measures 1-4e-8 / 1-9e-8); at configs[4]'s length the
-drift bound of tests/test_f32_drift_gpu.py holds unchanged.  Sharding and the association modes change WHERE a tile is updated and who
+(measured 0.4-6e-8 on x, 0.8-5e-9 on P, the same as the F64-arithmetic pass on the same float tiles); at configs[4]'s length the
+drift bound of tests/test_f32_drift_gpu.py holds unchanged, and at its real size AND length tests/test_full_size_gpu.py.  Sharding and the association modes change WHERE a tile is updated and who
 decides, not one operation on it: bit-identical to the plain engine of the same batch.  (The asynchronous pass is not, with float tiles of
 either arithmetic: the corrections that run beside a pass read the float tiles of BEFORE it plus its pairs in F64 -- unrounded -- where the
 synchronous engine reads the rounded result; it is held to the oracle tolerance instead.  With F64 tiles nothing is rounded and all

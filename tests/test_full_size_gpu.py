@@ -154,6 +154,25 @@ def test_ten_thousand_landmarks_eight_shards(oracle_lib):
     g.close(); one.close()
 
 
+def _f32_against_f64(e32, e64, cap, N0):
+    """max-norm relative errors of a float-tile engine against the F64-tile engine: x, the digests of P, the robot rows, sampled 6 x 6 blocks
+    on and off the diagonal incl. rows appended after the bulk load (the largest entries of P)."""
+    n = 3 + 2 * cap
+    x32, x64 = e32.get_x(), e64.get_x()
+    assert np.isfinite(x32).all()
+    ex = rel_err(x32, x64)
+    d32, d64 = e32.digest(), e64.digest()
+    ed = float(np.max(np.abs(d32 - d64) / np.abs(d64)))
+    er = rel_err(e32.get_P_block(0, 0, 3, n), e64.get_P_block(0, 0, 3, n))
+    rng = np.random.default_rng(3)
+    corners = [(3, 3), (3 + 2 * 127, 3), (3 + 2 * 20000, 3 + 2 * 19999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * N0, 3 + 2 * 123),
+               (3 + 2 * (N0 + 50), 3 + 2 * (N0 + 49))] + [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(24)]
+    blocks = [(e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)) for r0, c0 in corners]
+    scale = max(float(np.abs(b64).max()) for _, b64 in blocks)        # max-norm over the samples (they include appended diagonal blocks, the largest entries of P)
+    eb = max(float(np.abs(a - b64).max()) for a, b64 in blocks) / scale
+    return ex, ed, er, eb
+
+
 @pytest.mark.parametrize("storage,batch", [("f32", 12), ("f32_mixed", 32)])
 def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles(storage, batch):
     """BASELINE.json configs[4]'s shape on one GPU: 40 000 landmarks bulk-loaded, F32 tile storage / F64 solve, every step =
@@ -199,19 +218,7 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles(stor
     assert e32.N == e64.N == cap
     passes = steps / batch + 2                              # + the two digests above
     tol = 2e-8                                              # measured 3e-9; DESIGN.md section 5 states 2e-9 + 6e-12 K for the max-norm over ALL entries
-    n = 3 + 2 * cap
-    x32, x64 = e32.get_x(), e64.get_x()
-    assert np.isfinite(x32).all()
-    ex = rel_err(x32, x64)
-    d32, d64 = e32.digest(), e64.digest()
-    ed = float(np.max(np.abs(d32 - d64) / np.abs(d64)))
-    er = rel_err(e32.get_P_block(0, 0, 3, n), e64.get_P_block(0, 0, 3, n))
-    rng = np.random.default_rng(3)
-    corners = [(3, 3), (3 + 2 * 127, 3), (3 + 2 * 20000, 3 + 2 * 19999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * N0, 3 + 2 * 123),
-               (3 + 2 * (N0 + 50), 3 + 2 * (N0 + 49))] + [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(24)]
-    blocks = [(e32.get_P_block(r0, c0, 6, 6), e64.get_P_block(r0, c0, 6, 6)) for r0, c0 in corners]
-    scale = max(float(np.abs(b64).max()) for _, b64 in blocks)        # max-norm over the samples (they include appended diagonal blocks, the largest entries of P)
-    eb = max(float(np.abs(a - b64).max()) for a, b64 in blocks) / scale
+    ex, ed, er, eb = _f32_against_f64(e32, e64, cap, N0)
     rec = {"landmarks": [N0, cap], "storage": storage, "update_steps": steps, "deferred_batch": batch, "passes_over_P": passes, "tolerance": tol,
            "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er, "rel_err_sampled_blocks": eb,
            "trace_before_after_last_correction": traces}
@@ -222,3 +229,63 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles(stor
             json.dump(rec, fh)
     assert ex <= tol and ed <= tol and er <= tol and eb <= tol, rec
     e64.close(); e32.close()
+
+
+def test_config5_at_its_real_size_and_length():
+    """BASELINE.json configs[4] as SURVEY.md 8d states it, on one GPU: 40 000 landmarks bulk-loaded, every step = predict + append of one
+    new landmark + one correction, UNTIL 50 000 -- 10 000 update-steps -- with float tiles in both arithmetics (F64-arithmetic pass at batch 12,
+    F32-arithmetic pass on the matrix pipe at batch 64) against the F64-tile engine (batch 20) on the same inputs.  The tolerance stated in
+    DESIGN.md section 5 for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x, gives 6.2e-8 / 2.1e-8 here: asserted on x, the digests of P, the robot
+    rows and the sampled blocks (which include the appended diagonal blocks, the largest entries).  BASELINE.json's 1e-6 is held with a margin of 15."""
+    import ctypes, json, os
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.world import World
+    N0, steps = 40000, 10000
+    cap = N0 + steps
+    w = World(cap, 20260101 + 5)
+    rng = np.random.default_rng(77)
+    n0 = 3 + 2 * N0
+    x = np.concatenate([[0.0, 0.0, 0.0], w.landmarks[:N0].reshape(-1)])
+    d = rng.uniform(0.01, 0.1, n0)
+    U = rng.normal(0.0, 0.01, (n0, 8))
+    s = np.arange(1, N0 + 1.0)
+    eng = {"f64": Engine(mode="known", capacity=cap, storage="f64", batch=20), "f32": Engine(mode="known", capacity=cap, storage="f32", batch=12),
+           "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64)}
+    for e in eng.values():
+        e.load_lowrank_state(x, s, d, U)
+    Rc = [.01, 5.0]
+    plan = []
+    for t in range(steps):
+        u = w.step()
+        k = (t * 37) % N0
+        (_, r, b), = w.observe([k])
+        plan.append((u, np.array([r, b]), np.diag([r * Rc[0], b * Rc[1]]), k))
+    POS = np.ascontiguousarray(w.landmarks[N0:N0 + steps], dtype=np.float64)
+    for e in eng.values():                                   # the C ABI driven directly (Engine.marshal_steps), as scripts/bench_config5.py does
+        m = e.marshal_steps(plan)
+        f_pred, f_corr = e._raw[0], e._raw[1]
+        f_app = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double)(("ekf_append", e.lib))
+        for i in range(steps):
+            rc = f_pred(e.h, m["u"] + 16 * i) or f_app(e.h, m["u"] + 16 * i, m["r"] + 32 * i, POS.ctypes.data + 16 * i, float(N0 + i + 1)) \
+                or f_corr(e.h, m["z"] + 16 * i, m["r"] + 32 * i, m["k"][i])
+            if rc:
+                e._check(rc)
+        e.flush(); e.sync()
+        assert e.N == cap
+    tol_x, tol_P = 1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps
+    rec = {"landmarks": [N0, cap], "update_steps": steps, "tolerance_x": tol_x, "tolerance_P": tol_P}
+    for name in ("f32", "f32_mixed"):
+        ex, ed, er, eb = _f32_against_f64(eng[name], eng["f64"], cap, N0)
+        rec[name] = {"deferred_batch": int(eng[name].cfg.batch), "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er,
+                     "rel_err_sampled_blocks": eb}
+    print("configs[4] at full size and length: %s" % json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_full_length.json"), "w") as fh:
+            json.dump(rec, fh)
+    for name in ("f32", "f32_mixed"):
+        r = rec[name]
+        assert r["rel_err_x"] <= tol_x and r["rel_err_digest_trace_sum_sumsq"] <= tol_P and r["rel_err_robot_rows"] <= tol_P \
+            and r["rel_err_sampled_blocks"] <= tol_P, rec
+    for e in eng.values():
+        e.close()
