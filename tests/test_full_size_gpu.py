@@ -289,3 +289,67 @@ def test_config5_at_its_real_size_and_length():
             and r["rel_err_sampled_blocks"] <= tol_P, rec
     for e in eng.values():
         e.close()
+
+
+@pytest.mark.parametrize("storage,batch", [("f32", 12), ("f32_mixed", 32)])
+def test_config5_shape_eight_shards_equal_the_single_gpu_engine_bitwise(storage, batch):
+    """BASELINE.json configs[4] is an 8-GPU configuration: 40 000 landmarks, float tiles, streaming append, P split over 8 shards (all on the one
+    test GPU, one process: ekf_exchange_local; the kernels are the ones a multi-GPU run launches).  Two batches of predict + append + correction with
+    the per-step exchange (k_rowpanel<float> patches the pending pairs), then one batch through ONE prefetch exchange -- against the unsharded
+    float-tile engine of the same arithmetic and batch: x bit for bit on every shard, digests summed over the shards, sampled blocks merged from the
+    owning shards bit for bit (sharding changes where a tile lives, not one operation on it)."""
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    from ekf_slam_amd.world import World
+    N0, world = 40000, 8
+    steps = 2 * batch
+    cap = N0 + steps
+    w = World(cap, 20260101 + 5)
+    rng = np.random.default_rng(77)
+    n0 = 3 + 2 * N0
+    x = np.concatenate([[0.0, 0.0, 0.0], w.landmarks[:N0].reshape(-1)])
+    d = rng.uniform(0.01, 0.1, n0)
+    U = rng.normal(0.0, 0.01, (n0, 8))
+    s = np.arange(1, N0 + 1.0)
+    one = Engine(mode="known", capacity=cap, storage=storage, batch=batch)
+    g = ShardGroup(world, mode="known", capacity=cap, storage=storage, batch=batch)
+    for e in (one, g):
+        e.load_lowrank_state(x, s, d, U)
+    Rc = [.01, 5.0]
+    for t in range(steps):
+        u = w.step()
+        k = (t * 37) % N0 if t % 5 else N0 + t - 1            # every fifth correction names the landmark appended one step earlier
+        if t == 0:
+            k = 17
+        (_, r, b), = w.observe([k])
+        R = np.diag([r * Rc[0], b * Rc[1]])
+        for e in (one, g):
+            e.predict(u)
+            e.append(u, R, w.landmarks[N0 + t], N0 + t + 1)
+            e.correct([r, b], R, k)
+    assert one.N == g.N == cap
+    plan = [3, 39999, N0 + 5, 3, 20000, cap - 1, 12345, 77][:min(batch, 8)]
+    g.flush(); one.flush()
+    g.prefetch_rows(sorted(set(plan)))
+    for k in plan:
+        u = w.step()
+        (_, r, b), = w.observe([k])
+        R = np.diag([r * Rc[0], b * Rc[1]])
+        one.predict(u); one.correct([r, b], R, k)
+        g.predict(u); g.correct_local([r, b], R, k)
+    xs = g.get_x()                                             # asserts the replicated x is identical on all 8 shards
+    np.testing.assert_array_equal(xs, one.get_x())
+    np.testing.assert_allclose(sum(np.asarray(e.digest()) for e in g.shards), one.digest(), rtol=1e-12)
+    n = 3 + 2 * cap
+    rng = np.random.default_rng(4)
+    corners = [(3, 3), (3 + 2 * 127, 3), (3 + 2 * 20000, 3 + 2 * 19999), (n - 6, 5), (n - 6, n - 6), (3 + 2 * N0, 3 + 2 * 123)] + \
+              [tuple(int(v) for v in rng.integers(3, n - 8, 2)) for _ in range(20)]
+    for r0, c0 in corners:
+        a = one.get_P_block(r0, c0, 6, 6)
+        merged = np.full((6, 6), np.nan)
+        for e in g.shards:
+            blk = e.get_P_block(r0, c0, 6, 6)
+            hole = np.isnan(merged)
+            merged[hole] = blk[hole]
+        np.testing.assert_array_equal(merged, a)
+    g.close(); one.close()
