@@ -18,6 +18,9 @@ peak can be checked on each):
     every correction has been applied to every entry of P inside it.
   * N > 1 only, `deferred_lookahead`: the same with the next batch's landmarks announced (ekf_prefetch_rows): one
     all-gather per batch instead of one per update-step.
+  * N = 1 only, `other_configs` (after the legs above, each in a child process; --no-other-configs skips it): BASELINE.json's other
+    single-GPU configurations -- configs[1] (1 000 landmarks, unknown correspondence, the device-resident measure loop) and the whole
+    configs[4] workload on one GPU (40 000 -> 50 000 landmarks, float tiles, the pass in F32 arithmetic): their own JSON lines, verbatim.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks 10000] [--tile 128] [--batch 32]
 
@@ -154,6 +157,31 @@ def load_committed_pmc(N, tile, pairs):
     return None
 
 
+def other_configs(timeout_s=300):
+    """BASELINE.json's other single-GPU configurations, measured in the same invocation (each in a fresh child process, after the headline
+    legs; a failure there is reported in its own entry and never touches the headline): configs[1] -- 1 000 landmarks, unknown
+    correspondence, the device-resident measure loop (scripts/bench_config2.py) -- and configs[4]'s whole workload on ONE GPU -- 40 000
+    landmarks bulk-loaded, predict + append + correction per step until 50 000, float tiles, the pass in F32 arithmetic at batch 64
+    (scripts/bench_config5.py).  Parity of both is the test suite's business (tests/test_config2_uc_gpu.py, tests/test_full_size_gpu.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    runs = (("configs[1]", ["scripts/bench_config2.py", "--batch", "8"]),
+            ("configs[4] on one GPU", ["scripts/bench_config5.py", "--storage", "f32_mixed", "--batch", "64", "--landmarks", "40000",
+                                       "--steps", "9936", "--warmup", "64"]))
+    out = {}
+    for key, cmd in runs:
+        try:
+            r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout_s, cwd=root)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                out[key] = json.loads(lines[-1])
+            else:
+                out[key] = {"error": "exit code %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:200] if r.stderr.strip() else "")}
+        except Exception as exc:                               # a leg beside the headline: report, never raise
+            out[key] = {"error": repr(exc)[:200]}
+    return out
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes.  Nothing in this
     process has touched HIP or torch (never re-exec a process that initialised the GPU)."""
@@ -199,6 +227,8 @@ def main():
                          "communicator, sharded gather; cfg.force_sharded) -- the per-step fixed cost of a shard, measurable on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deferred", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` entry (configs[1] and configs[4]'s workload on one GPU, each run in a child process)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -425,6 +455,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(N, x, s, d, U, steps[args.warmup:])
             # SURVEY.md 8d asks for both restatements beside the GPU figure: [0] the primary above, [1] the literal-dense one
             out["cpu_baselines"] = [out["cpu_baseline"], cpu_baseline_dense(N, seed, Rc)]
+        if world == 1 and not args.no_other_configs and not forced:
+            out["other_configs"] = other_configs()
         timed_s = head["ms_per_step"] * 1e-3 * args.steps
         if args.steps < 256:
             out["config"]["note"] = ("--steps %d: the timed region of the headline leg is %.3f s (< 0.2 s); the 1 280-step default "

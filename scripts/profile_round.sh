@@ -10,9 +10,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 $REPO/scripts/show_bench.py $OUT/bench.json
-ARGS="--steps 160 --warmup 64 --deferred-steps 640 --no-cpu-baseline"
+ARGS="--steps 160 --warmup 64 --deferred-steps 640 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
-ARGS="--steps 64 --warmup 32 --deferred-steps 256 --no-cpu-baseline"
+ARGS="--steps 64 --warmup 32 --deferred-steps 256 --no-cpu-baseline --no-other-configs"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err
 if [ "${MFMA:-0}" = "1" ]; then

@@ -17,7 +17,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--landmarks", "1500", "--steps", "64", "--warmup", "16", "--batch", "8", "--deferred-steps", "64", "--no-cpu-baseline"]
+ARGS = ["--landmarks", "1500", "--steps", "64", "--warmup", "16", "--batch", "8", "--deferred-steps", "64", "--no-cpu-baseline", "--no-other-configs"]
 
 
 def _bench(n, extra_env=None, extra_args=()):
