@@ -1873,16 +1873,16 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
 // Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
 // = 64 rows x one 128-column half; a lane's 16 bytes are 4 columns, widened to f64 on load and rounded once on store).
-template <typename TS, int T, int kChunk>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChunk <= 4 ? 4 : 3, kChunk <= 4 ? 4 : 3)))
+template <typename TS, int T, int kChunk, int kCols = 128, int kWpe = (kChunk <= 4 ? 4 : 3)>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
 void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
                   const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
                   int npairs, TileMap tm) {
-    constexpr int kRows = 64, kCols = 128, kKPad = kRows + 16;
+    constexpr int kRows = 64, kKPad = kRows + 16;
     constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
     constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
     constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
-    static_assert(kBP * kE == 8 && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 columns = 8 MFMA blocks");
+    static_assert((kBP * kE == 8 || kBP * kE == 4) && T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 rows x 128 (64) columns = 8 (4) MFMA blocks");
     static_assert(kChunk % 2 == 0 && (kChunk * kCols) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
     __shared__ __attribute__((aligned(16))) double Gs[2 * kChunk][kCols];
     __shared__ double Ks[2 * kChunk][kKPad];
@@ -1918,7 +1918,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
                 const int e = tid + q * kBlock, col = e & (kCols - 1);
-                const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;      // clamp: always a valid pair, used only if in range
+                const int i = (e / kCols) < cn ? (e / kCols) : cn - 1;      // clamp: always a valid pair, used only if in range
                 tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
             }
 #pragma unroll
@@ -1934,7 +1934,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
             __syncthreads();                                          // everyone is done with the previous chunk
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
-                const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
+                const int e = tid + q * kBlock, i = e / kCols, col = e & (kCols - 1);
                 if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
                 else if (i == cn) { Gs[2 * i][col] = 0.0; Gs[2 * i + 1][col] = 0.0; }       // pad of an odd count
             }
@@ -2154,6 +2154,20 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                 // three wavefronts per SIMD (all sixteen tile pieces of a wavefront in flight at the end) for the HBM-bound small counts, four beyond
                 if (npairs <= 4) EKF_M32(4, 2, 3); else EKF_M32(4, 2, 4);
 #undef EKF_M32
+                return true;
+            }
+        }
+        if constexpr (sizeof(TS) == 8) {
+            // Up to 12 pairs the pass is HBM-bound and gains from finer work items: 64 rows x 64 columns (32 KiB, 4 accumulator blocks per wavefront,
+            // five wavefronts per SIMD) -- 0.543 against 0.566 ms at 2-8 pairs, 10 000 landmarks; from ~16 pairs on the 128-column items win (G is read
+            // from L2 once per 128 instead of 64 columns: 20 pairs 0.554 against 0.564).  profiles/round3_tuning.md 37.
+            static const int half_max = ekf_tune_int("EKF_FLUSH_HALF_MAX", 12);
+            if (npairs <= half_max) {
+                int64_t g2 = 8 * xcd_len * (T / 64) * (T / 64);
+                if (grid_cap > 0 && g2 > grid_cap) g2 = grid_cap;
+                hipLaunchKernelGGL((k_flush_mfma<TS, T, 4, 64, 5>), dim3((unsigned)g2), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
+                                   work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
+                if (kname) snprintf(kname, 64, "k_flush_mfma<double,%d,4,64>", T);
                 return true;
             }
         }

@@ -58,7 +58,7 @@ def main():
     print(json.dumps({"label": a.label, "landmarks": N, "batch": a.batch, "kernel": name, "pairs": pairs, "launches": nl,
                       "flush_ms": round(avg, 4), "frac": round(b_alg / (avg * 1e-3) / 8e12, 4) if avg > 0 else None,
                       "gather_us": round(gms / max(ng, 1) * 1e3, 2), "steps_per_s": round(nsteps / dt),
-                      "finite": bool(np.isfinite(e.get_x()).all())}), flush=True)
+                      "finite": bool(np.isfinite(e.get_x()).all()), "digest": [float(v) for v in e.digest()]}), flush=True)
     e.close()
 
 
