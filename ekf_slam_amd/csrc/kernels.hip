@@ -1868,7 +1868,8 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // for every x, signed zeros included).
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// Two chunk sizes: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~30 pairs (28 pairs: 0.603 vs 0.634 ms; 32: 0.651 vs 0.627), where the pass is
+// Work items: 64 rows x kCols columns -- kCols = 64 (4 accumulator blocks per wavefront, five wavefronts per SIMD) up to 12 pairs, 128 beyond
+// (launch_flush_mfma).  Two chunk sizes for the 128-column items: chunks of 4 pairs fit 4 wavefronts per SIMD (122 VGPRs) and win up to ~30 pairs (28 pairs: 0.603 vs 0.634 ms; 32: 0.651 vs 0.627), where the pass is
 // HBM-bound and occupancy hides the tile latency; chunks of 8 pairs (3 wavefronts per SIMD, half the barriers) win beyond,
 // where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
 // Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
