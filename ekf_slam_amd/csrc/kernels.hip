@@ -1989,7 +1989,7 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 // instruction's result layout differs from the f64 one's: lane (lr, lc) register r is row 4 lr + r (f64: lr + 4 r) of column block lc.
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
-template <int T, int kChunk, int kRG, int kWpe>
+template <int T, int kChunk, int kRG, int kWpe, bool kEarly = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
 void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
                     const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
@@ -2084,21 +2084,38 @@ void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, co
         };
         auto count = [&](int c0) { return npairs - c0 < kChunk ? npairs - c0 : kChunk; };
         fetch(0, count(0));
-        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+        int c0 = 0;
+        for (; c0 + kChunk < npairs; c0 += kChunk) {
             __syncthreads();                                          // everyone is done with the previous chunk
             stage(count(c0));
             __syncthreads();
-            if (c0 + kChunk < npairs) fetch(c0 + kChunk, count(c0 + kChunk));
+            fetch(c0 + kChunk, count(c0 + kChunk));
             apply(count(c0));
         }
+        __syncthreads();                                              // the last chunk, peeled: nothing is fetched behind it ...
+        stage(count(c0));
+        __syncthreads();
+        f4_t te[kEarly ? kRG : 1][2][4];                              // ... kEarly: the tile is requested HERE, in front of the last chunk's matrix work
+        if constexpr (kEarly) {
+#pragma unroll
+            for (int rg = 0; rg < kRG; ++rg)
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        te[rg][bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
+        }
+        apply(count(c0));
 #pragma unroll
         for (int rg = 0; rg < kRG; ++rg) {
             f4_t tl[2][4];
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    tl[bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (kEarly) tl[bp][r] = te[rg][bp][r];
+                    else tl[bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
+                }
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
@@ -2136,24 +2153,36 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if constexpr (sizeof(TS) == 4) {
-            if (arith == 1) {                                         // cfg.pass_arith = EKF_ARITH_F32: the f32 matrix pipe
+            if (arith == 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32: the f32 matrix pipe (one or two pairs: the pass is
+                                                                      // purely HBM-bound and the F64-arithmetic kernel below streams it 5 % faster, 4.0 against 4.3 ms at 40 k)
 #define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
                                   hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \
                                            (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
                                   if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d>", T, CH, RG, WPE); } while (0)
+#define EKF_M32E(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
+                                  hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE, true>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \
+                                           (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                                  if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d,early>", T, CH, RG, WPE); } while (0)
 #ifdef EKF_TUNING
-                const int v = 100 * ekf_tune_int("EKF_MFMA32_RG", 0) + 10 * ekf_tune_int("EKF_MFMA32_CHUNK", 4) + ekf_tune_int("EKF_MFMA32_WPE", 4);
+                const int v = (ekf_tune_int("EKF_MFMA32_EARLY", 0) ? 1 : 0) + (ekf_tune_int("EKF_MFMA32_EARLY", 0) ? 10 : 1) *
+                              (100 * ekf_tune_int("EKF_MFMA32_RG", 0) + 10 * ekf_tune_int("EKF_MFMA32_CHUNK", 4) + ekf_tune_int("EKF_MFMA32_WPE", 4));
                 switch (v) {
                     case 144: EKF_M32(4, 1, 4); return true;
                     case 146: EKF_M32(4, 1, 6); return true;
                     case 184: EKF_M32(8, 1, 4); return true;
                     case 243: EKF_M32(4, 2, 3); return true;
                     case 244: EKF_M32(4, 2, 4); return true;
+                    case 2431: EKF_M32E(4, 2, 3); return true;       // + early tile request (EKF_MFMA32_RG=24 encodes "2, early")
+                    case 2441: EKF_M32E(4, 2, 4); return true;
+                    case 2421: EKF_M32E(4, 2, 2); return true;
                     default: break;
                 }
 #endif
-                // three wavefronts per SIMD (all sixteen tile pieces of a wavefront in flight at the end) for the HBM-bound small counts, four beyond
-                if (npairs <= 4) EKF_M32(4, 2, 3); else EKF_M32(4, 2, 4);
+                // three wavefronts per SIMD; from five pairs on the tile is requested in front of the LAST chunk's matrix work instead of after it
+                // (its 64 registers are free once nothing is fetched any more): 5.37 against 5.63-5.67 ms at 32 pairs, 4.07 against 4.11-4.20 at 12,
+                // equal at 64 (profiles/round3_tuning.md 40)
+                if (npairs <= 4) EKF_M32(4, 2, 3); else EKF_M32E(4, 2, 3);
+#undef EKF_M32E
 #undef EKF_M32
                 return true;
             }

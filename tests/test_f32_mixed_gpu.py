@@ -63,8 +63,9 @@ def test_f32_arithmetic_pass_against_f64_oracle(batch, oracle_lib):
         q.set_state(x, P, s)
     _run([e, plain], ref, 40, 14, appends=(11, 29))
     e.flush()
-    name, pairs = e.downdate_kernel_name()
-    assert name.startswith("k_flush_mfma32<256,") and plain.downdate_kernel_name()[0].startswith("k_flush_mfma<float,256,")
+    name, pairs = e.downdate_kernel_name()                   # the run's last pass: 40 % batch pairs (one or two pairs take the F64-arithmetic kernel)
+    assert name.startswith("k_flush_mfma32<256," if pairs > 2 else "k_flush_mfma<float,256,"), (name, pairs)
+    assert plain.downdate_kernel_name()[0].startswith("k_flush_mfma<float,256,")
     ex, eP = rel_err(e.get_x(), ref.x), rel_err(e.get_P(), ref.P)
     px, pP = rel_err(plain.get_x(), ref.x), rel_err(plain.get_P(), ref.P)
     print("f32 arithmetic, batch %d: x %.2e P %.2e   (F64 arithmetic on the same tiles: x %.2e P %.2e)" % (batch, ex, eP, px, pP))
