@@ -1,0 +1,31 @@
+"""GPU: the default single-GPU bench line as the driver runs it (a fresh child process, never an exec from this one): ONE JSON line that carries the headline
+with `roofline` and -- measured in the same invocation, each in a child process of its own -- BASELINE.json's other single-GPU configurations under
+`other_configs`: configs[1] (1 000 landmarks, unknown correspondence, the device-resident measure loop) and the whole configs[4] workload on one GPU
+(40 000 -> 50 000 landmarks, float tiles, the pass in F32 arithmetic).  Short legs here (the figures to quote come from the default run); no CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_default_bench_line_carries_the_other_single_gpu_configurations():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "64", "--warmup", "16", "--deferred-steps", "80", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    b = json.loads(lines[0])
+    assert b["n_gpus"] == 1 and b["unit"] == "update-steps/s" and b["value"] > 0 and b["config"]["state_finite"]
+    assert b["roofline"]["bound"] == "hbm" and 0.5 < b["roofline"]["frac"] < 1.0 and "k_downdate_w" in b["roofline"]["kernel"]
+    assert "note" in b["config"]                                            # --steps < 256: the line says that its timed region is short
+    oc = b["other_configs"]
+    c1, c4 = oc["configs[1]"], oc["configs[4] on one GPU"]
+    assert "error" not in c1 and "error" not in c4, oc
+    assert c1["value"] > 5e4 and c1["config"]["state_finite"] and "device-resident loop" in c1["config"]["device_association"]
+    assert c4["value"] > 1e3 and c4["config"]["state_finite"] and c4["roofline"]["kernel"].startswith("k_flush_mfma32<256,")
+    assert c4["steps"] == 9936 and "50000 landmarks" in c4["config"]["workload"]
