@@ -489,9 +489,7 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
                   const DevLoopArgs *dl = nullptr) {
     REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
     {
-        int32_t rcp = materialize_predict(h);
-        if (rcp) return rcp;
-        rcp = retire_inflight(h);          // the new rows must land in the store every later kernel reads
+        const int32_t rcp = retire_inflight(h);          // the new rows must land in the store every later kernel reads
         if (rcp) return rcp;
     }
     AppendArgs a;
@@ -499,8 +497,13 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
     a.pos0 = pos[0]; a.pos1 = pos[1]; a.signature = signature; a.N = h->N; a.cur = h->cur;
     {
+        // a recorded predict is carried out by the append launch itself (k_append<.., kPredict>): the state moves to the other buffer
+        PredictArgs pa = h->pp;
+        pa.n_mm = n_mm(h); pa.cur = h->cur;
+        const PredictArgs *fuse = h->have_pp ? &pa : nullptr;
         TimedLaunch tl(h, EKF_KERNEL_APPEND);
-        HIPCHK(h, launch_append(h->st, a, h->storage, h->stream, dl));
+        HIPCHK(h, launch_append(h->st, a, h->storage, h->stream, dl, fuse));
+        if (fuse) { h->have_pp = false; h->cur ^= 1; }
     }
     if ((int64_t)h->s_host.size() > h->N) { h->s_host.resize((size_t)h->N); h->s_sorted_ok = false; }
     h->s_host.push_back(signature);

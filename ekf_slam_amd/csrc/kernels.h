@@ -131,7 +131,8 @@ constexpr int kAssocBlock = 256;       // 4 wavefronts = one per SIMD: the per-l
 
 hipError_t launch_predict(const DevState &st, const PredictArgs &a, int storage, hipStream_t s);
 // dl != nullptr (device-resident measure loop): the kernel also reduces dl->parts_in and records the decision in dl->rec
-hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dl = nullptr);
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dl = nullptr,
+                         const PredictArgs *fused_predict = nullptr);
 // fused_predict != nullptr folds predict(u) into the correction (one launch instead of two, identical arithmetic)
 // fuse_downdate: the kernel also applies its pair to the landmark block (small maps: a.n_mm <= gather_fuse_max_rows(), one
 // workgroup); the pair is then NOT written to the pending ring and no downdate launch must follow

@@ -316,9 +316,24 @@ template <> struct DevLoopParam<true> { using type = DevLoopArgs; };
 // ---------------------------------------------------------------------------------------------------
 // append: in place on buffer `cur` (only new slots are written)
 // ---------------------------------------------------------------------------------------------------
-template <typename TS>
-__global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, DevLoopArgs dl) {
+// kPredict: a recorded predict(u) (ekf_predict is lazy) is carried out by THIS launch -- every workgroup's first lane runs the small 3x3 part
+// (as k_predict does), every column lane predicts its strip column (predict_strip: the same two FMAs as k_predict / k_predict_mfma) and copies
+// its x entry, everything is written to the other state buffer (a.cur ^ 1), and the append itself reads the predicted values: predict -> append
+// costs one launch instead of two, same bits (tests/test_deferred_gpu.py).
+template <typename TS, bool kPredict = false>
+__global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, DevLoopArgs dl, PredictArgs pa) {
+    __shared__ PredictSmall aps;
     const int cur = a.cur;
+    const int out = kPredict ? (cur ^ 1) : cur;                  // the buffer this launch leaves the state in
+    if constexpr (kPredict) {
+        if (threadIdx.x == 0) {
+            const double pose[3] = { st.x[cur][0], st.x[cur][1], st.x[cur][2] };
+            double prr_in[9];
+            for (int i = 0; i < 9; ++i) prr_in[i] = st.prr[cur][i];
+            predict_small(pose, prr_in, pa.u0, pa.u1, pa.C, aps);
+        }
+        __syncthreads();
+    }
     if (dl.parts_in != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
         // device-resident measure loop: the association of this observation must have found nothing below the threshold
         // (EKF_SLAM_UC.m:121); what it did find goes to the host's record
@@ -327,17 +342,24 @@ __global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, De
         reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, (int)threadIdx.x, dll, dix);
         if (threadIdx.x == 0) store_partial(dl.rec, dll, dix, dl.seq_rec);
     }
-    double *__restrict__ x = st.x[cur];
-    double *__restrict__ s = st.strip[cur];
-    const double *__restrict__ prr = st.prr[cur];
+    double *__restrict__ x = st.x[out];
+    double *__restrict__ s = st.strip[out];
+    const double *__restrict__ prr = kPredict ? aps.prr : st.prr[cur];
     TS *__restrict__ tiles = (TS *)st.tiles;
     const int64_t n_mm = 2 * a.N;          // old landmark-block size; new rows are n_mm, n_mm + 1
     const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const double th = x[2];                // post-predict heading (EKF_SLAM.m:84-85)
+    const double th = kPredict ? aps.pose[2] : x[2];             // post-predict heading (EKF_SLAM.m:84-85)
     const double jxr[2][3] = { { 1, 0, -a.u0 * ekfm::sind(th) }, { 0, 1, a.u0 * ekfm::cosd(th) } };
     if (c < n_mm) {
         // F: P(new, lm) = jxr * P(lm, 1:3)'   (EKF_SLAM.m:95); the column strip equals the row strip here
-        const double s0 = s[c], s1 = s[st.ldm + c], s2 = s[2 * st.ldm + c];
+        const double *__restrict__ sin_ = st.strip[cur];
+        double s0 = sin_[c], s1 = sin_[st.ldm + c];
+        const double s2 = sin_[2 * st.ldm + c];
+        if constexpr (kPredict) {
+            predict_strip(s0, s1, s2, aps.fa, aps.fb);
+            s[c] = s0; s[st.ldm + c] = s1; s[2 * st.ldm + c] = s2;
+            x[3 + c] = st.x[cur][3 + c];
+        }
         for (int i = 0; i < 2; ++i) {
             const double v = jxr[i][0] * s0 + jxr[i][1] * s1 + jxr[i][2] * s2;
             if (st.tm.mine((n_mm + i) >> st.tm.shift, c >> st.tm.shift))
@@ -345,6 +367,10 @@ __global__ __launch_bounds__(kBlock) void k_append(DevState st, AppendArgs a, De
         }
     }
     if (c == 0) {
+        if constexpr (kPredict) {
+            for (int i = 0; i < 9; ++i) { st.prr[out][i] = aps.prr[i]; st.small[12 + i] = aps.Q[i]; }
+            for (int i = 0; i < 3; ++i) x[i] = aps.pose[i];
+        }
         x[3 + n_mm] = a.pos0;                                                         // EKF_SLAM.m:79
         x[3 + n_mm + 1] = a.pos1;
         st.s[a.N] = a.signature;                                                      // EKF_SLAM.m:70
@@ -1754,14 +1780,23 @@ hipError_t launch_predict(const DevState &st, const PredictArgs &a, int, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dlp) {
+hipError_t launch_append(const DevState &st, const AppendArgs &a, int storage, hipStream_t s, const DevLoopArgs *dlp,
+                         const PredictArgs *fused_predict) {
     const int64_t n_mm = 2 * a.N;
     const int64_t grid = cdiv(n_mm > 0 ? n_mm : 1, kBlock);
     DevLoopArgs dl = {};
     if (dlp) dl = *dlp;
-    EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_append<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl),
-        hipLaunchKernelGGL(k_append<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl));
+    PredictArgs pa = {};
+    if (fused_predict) {
+        pa = *fused_predict;
+        EKF_STORAGE_DISPATCH(storage,
+            hipLaunchKernelGGL((k_append<double, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl, pa),
+            hipLaunchKernelGGL((k_append<float, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl, pa));
+    } else {
+        EKF_STORAGE_DISPATCH(storage,
+            hipLaunchKernelGGL((k_append<double, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl, pa),
+            hipLaunchKernelGGL((k_append<float, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, a, dl, pa));
+    }
     return hipGetLastError();
 }
 

@@ -151,6 +151,44 @@ def test_fused_predict_equals_standalone_predict_bitwise(oracle_lib):
     assert rel_err(fused.get_P(), ref.P) < REL and rel_err(fused.get_x(), ref.x) < REL
 
 
+@pytest.mark.parametrize("N,tile,batch,storage", [(0, 16, 1, "f64"), (5, 16, 1, "f64"), (130, 64, 4, "f64"), (1100, 0, 2, "f64"), (300, 0, 8, "f32")])
+def test_predict_folded_into_append_equals_standalone_predict_bitwise(N, tile, batch, storage, oracle_lib):
+    """predict -> append (the streaming-append step of BASELINE configs[4], and a new landmark on a scan's first row): the append launch
+    carries the recorded predict out itself (k_append<.., kPredict>).  Forcing the standalone predict kernel first (any read of x
+    materialises it; k_predict_mfma at >= 1024 landmarks) must not change a single bit; both follow the oracle."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    cap = N + 12
+    fused = Engine(capacity=cap, tile=tile, batch=batch, storage=storage)
+    split = Engine(capacity=cap, tile=tile, batch=batch, storage=storage)
+    ref = StructuredEKF(cap, "known")
+    if N:
+        x, P, s = _state(N, 57)
+        for e in (fused, split, ref):
+            e.set_state(x, P, s)
+    rng = np.random.default_rng(21)
+    for step in range(9):
+        u = [0.1 + 0.02 * step, 7.0 * step - 13.0]
+        fused.predict(u); split.predict(u); ref.predict(u)
+        split.get_x()                                   # materialises the predict on its own
+        if step == 4:
+            fused.predict(u); split.predict(u); ref.predict(u)      # two predicts in a row: the first one is materialised by the second
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        pos = rng.uniform(-5, 5, 2)
+        fused.append(u, R, pos, fused.N + 1); split.append(u, R, pos, split.N + 1); ref.append(u, R, pos, ref.N + 1)
+        if step % 2:
+            idx0 = int(rng.integers(0, fused.N))
+            fused.correct(z, R, idx0); split.correct(z, R, idx0); ref.correct(z, R, idx0 + 1)
+    assert fused.N == split.N == ref.N == N + 9
+    np.testing.assert_array_equal(fused.get_Q3(), split.get_Q3())
+    np.testing.assert_array_equal(fused.get_x(), split.get_x())
+    np.testing.assert_array_equal(fused.get_P(), split.get_P())
+    np.testing.assert_array_equal(fused.get_s(), split.get_s())
+    tol = REL if storage == "f64" else 1e-6
+    assert rel_err(fused.get_P(), ref.P) < tol and rel_err(fused.get_x(), ref.x) < tol
+
+
 def test_mfma_predict_panel_matches_valu_and_oracle(oracle_lib):
     """At >= 1024 landmarks the standalone predict runs its 3x3 * 3x2N panel product on v_mfma_f64_16x16x4_f64; the
     predict folded into a correction uses plain FMAs.  The f64 MFMA is a k-ordered chain of correctly rounded FMAs
