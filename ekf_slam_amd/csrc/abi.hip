@@ -1048,6 +1048,11 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     // ONE allocation, G pairs then K pairs: k_gather addresses both from one uniform base with 32-bit lane offsets
     HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap * 2));
     h->st.Kp = h->st.Gp + (size_t)(2 * ldm) * h->st.pcap;
+    h->st.Gp32 = nullptr; h->st.Kp32 = nullptr;
+    if (cfg->pass_arith == EKF_ARITH_F32) {
+        HIPCHK(h, dalloc(h, &h->st.Gp32, (size_t)(2 * ldm) * h->st.pcap * 2));
+        h->st.Kp32 = h->st.Gp32 + (size_t)(2 * ldm) * h->st.pcap;
+    }
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));
     HIPCHK(h, dalloc(h, &h->d_work_xcd, (size_t)slots * 8));

@@ -31,6 +31,8 @@ struct DevState {
     // (pstart + i) mod pcap, i = 0 .. npend-1, oldest first.
     double *Gp;           // pending G pairs, then (same allocation) ...
     double *Kp;           // ... the pending K pairs: Kp = Gp + pcap * pair_stride (k_gather relies on a 32-bit offset between them)
+    float  *Gp32;         // cfg.pass_arith = EKF_ARITH_F32 only (nullptr otherwise): float copies of the same pairs, same slots and interleaving,
+    float  *Kp32;         // written by the gather beside the F64 ones -- what the F32-arithmetic pass reads (half the operand bytes)
     int64_t pair_stride;   // 2 * ldm
     int32_t pcap;          // slots in the ring
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)

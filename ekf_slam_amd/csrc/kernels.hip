@@ -1077,6 +1077,10 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         if (!kFused) {
             Gout[c] = make_double2(g[0], g[1]);
             Kout[c] = make_double2(k0, k1);
+            if (st.Gp32) {                                          // uniform: the F32-arithmetic pass reads float copies
+                reinterpret_cast<float2 *>(st.Gp32 + out_off)[c] = make_float2((float)g[0], (float)g[1]);
+                reinterpret_cast<float2 *>(st.Kp32 + out_off)[c] = make_float2((float)k0, (float)k1);
+            }
         }
         xn = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
         t0 = s0 - (sol.Kr[0][0] * g[0] + sol.Kr[0][1] * g[1]);
@@ -1091,6 +1095,10 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         // zero the tail of the last tile so the downdate leaves the unused part of edge tiles untouched
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
+        if (st.Gp32) {
+            reinterpret_cast<float2 *>(st.Gp32 + out_off)[c] = make_float2(0.0f, 0.0f);
+            reinterpret_cast<float2 *>(st.Kp32 + out_off)[c] = make_float2(0.0f, 0.0f);
+        }
     }
     // (4b) this correction's pair on the diagonal blocks, at once: P(I - K H) restricted to each landmark's own 2x2 block, rank2_apply in
     //      slot order like every pass -- the live copies never carry a pending pair.  ndc = the column's (c,c), ndl = (2k+1, 2k) on odd columns.
@@ -2027,7 +2035,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 template <int T, int kChunk, int kRG, int kWpe, bool kEarly = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
 void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
-                    const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
+                    const float *__restrict__ Kp, const float *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
                     int npairs, TileMap tm) {
     // kRG: 16-row groups per wavefront -- a workgroup owns 64 kRG rows x 128 columns (kRG = 2: twice the bytes in flight per workgroup and
     // one read of G from LDS for 16 instead of 8 MFMAs).  Production: kChunk = 4, kRG = 2, four wavefronts per SIMD (profiles/round3_tuning.md 36).
@@ -2069,32 +2077,32 @@ void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, co
         const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
         const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
         constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
-        double2 tg[kPerG], tk[kPerK];
+        float2 tg[kPerG], tk[kPerK];                                  // (the pairs' float copies, written by the gather: DevState::Gp32 / Kp32)
         auto fetch = [&](int c0, int cn) {
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
                 const int e = tid + q * kBlock, col = e & (kCols - 1);
                 const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;
-                tg[q] = reinterpret_cast<const double2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
+                tg[q] = reinterpret_cast<const float2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
             }
 #pragma unroll
             for (int q = 0; q < kPerK; ++q) {
                 const int e = tid + q * kBlock, row = e & (kRows - 1);
                 const int i = (e / kRows) < cn ? (e / kRows) : cn - 1;
-                tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
+                tk[q] = reinterpret_cast<const float2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
             }
         };
-        auto stage = [&](int cn) {                           // the fetched chunk, rounded to float, de-interleaved to [k][col] / [k][row]
+        auto stage = [&](int cn) {                           // the fetched chunk de-interleaved to [k][col] / [k][row]
 #pragma unroll
             for (int q = 0; q < kPerG; ++q) {
                 const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
-                if (i < cn) { Gs[2 * i][col] = (float)tg[q].x; Gs[2 * i + 1][col] = (float)tg[q].y; }
+                if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
                 else if (i == cn) { Gs[2 * i][col] = 0.0f; Gs[2 * i + 1][col] = 0.0f; }       // pad of an odd count
             }
 #pragma unroll
             for (int q = 0; q < kPerK; ++q) {
                 const int e = tid + q * kBlock, i = e / kRows, row = e & (kRows - 1);
-                if (i < cn) { Ks[2 * i][row] = -(float)tk[q].x; Ks[2 * i + 1][row] = -(float)tk[q].y; }
+                if (i < cn) { Ks[2 * i][row] = -tk[q].x; Ks[2 * i + 1][row] = -tk[q].y; }
                 else if (i == cn) { Ks[2 * i][row] = -0.0f; Ks[2 * i + 1][row] = -0.0f; }
             }
         };
@@ -2192,11 +2200,11 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                                                                       // purely HBM-bound and the F64-arithmetic kernel below streams it 5 % faster, 4.0 against 4.3 ms at 40 k)
 #define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
                                   hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \
-                                           (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                                           (float *)dstv, work_xcd, xcd_len, st.Kp32, st.Gp32, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
                                   if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d>", T, CH, RG, WPE); } while (0)
 #define EKF_M32E(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
                                   hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE, true>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \
-                                           (float *)dstv, work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                                           (float *)dstv, work_xcd, xcd_len, st.Kp32, st.Gp32, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
                                   if (kname) snprintf(kname, 64, "k_flush_mfma32<%d,%d,%d,%d,early>", T, CH, RG, WPE); } while (0)
 #ifdef EKF_TUNING
                 const int v = (ekf_tune_int("EKF_MFMA32_EARLY", 0) ? 1 : 0) + (ekf_tune_int("EKF_MFMA32_EARLY", 0) ? 10 : 1) *
@@ -2207,6 +2215,8 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                     case 184: EKF_M32(8, 1, 4); return true;
                     case 243: EKF_M32(4, 2, 3); return true;
                     case 244: EKF_M32(4, 2, 4); return true;
+                    case 2831: EKF_M32E(8, 2, 3); return true;
+                    case 2821: EKF_M32E(8, 2, 2); return true;
                     case 2431: EKF_M32E(4, 2, 3); return true;       // + early tile request (EKF_MFMA32_RG=24 encodes "2, early")
                     case 2441: EKF_M32E(4, 2, 4); return true;
                     case 2421: EKF_M32E(4, 2, 2); return true;
