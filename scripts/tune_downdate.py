@@ -29,10 +29,9 @@ print(json.dumps({"ms": best, "GBs": B / (best * 1e-3) / 1e9, "frac": B / (best 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 combos = [(64, s) for s in (8, 16, 32, 64)] + [(128, s) for s in (4, 8, 16, 32)] + [(32, 16), (32, 32), (16, 16)]
 for tile, slab in combos:
-    for nt in (0,):
-        for grid in (0,):
-            env = dict(os.environ, EKF_LIB_PATH=os.path.join(ROOT, 'ekf_slam_amd', 'libekfslam_tuning.so'),  # -DEKF_TUNING build: make -C ekf_slam_amd/csrc tuning
-                   EKF_DOWNDATE_NT=str(nt), EKF_DOWNDATE_GRID=str(grid), EKF_DOWNDATE_SLAB=str(slab))
-            out = subprocess.run([sys.executable, "-c", CHILD, str(N), str(tile)], env=env, capture_output=True, text=True)
-            line = out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else out.stderr[-300:]
-            print("tile %3d slab %3d nt %d grid %5d : %s" % (tile, slab, nt, grid, line), flush=True)
+    for grid in (0,):
+        env = dict(os.environ, EKF_LIB_PATH=os.path.join(ROOT, 'ekf_slam_amd', 'libekfslam_tuning.so'),  # -DEKF_TUNING build: make -C ekf_slam_amd/csrc tuning
+                   EKF_DOWNDATE_GRID=str(grid), EKF_DOWNDATE_SLAB=str(slab))
+        out = subprocess.run([sys.executable, "-c", CHILD, str(N), str(tile)], env=env, capture_output=True, text=True)
+        line = out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else out.stderr[-300:]
+        print("tile %3d slab %3d grid %5d : %s" % (tile, slab, grid, line), flush=True)
