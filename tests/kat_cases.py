@@ -319,3 +319,33 @@ class KatTable:
 
     def getLandmark(self, laserdata, x):
         return self._observed
+
+# KAT-15  append, then a correction of the landmark just appended -- the cross-covariances the append wrote are what the correction reads
+#     EKF_SLAM.m:67-98, then :124-145.   x = [0 0 90], P = .1 I3, no landmark;  append(u = [2 90], R = diag(.4, .125), pos = (0, 2), sig = 5)
+#     :84-88  heading 90: jxr = [1 0 -2; 0 1 0],  jz = [cosd90 -2 sind90; sind90 2 cosd90] = [0 -2; 1 0]
+#     :91     jxr Prr jxr' = .1 [1+4 0; 0 1] = diag(.5, .1);  jz R jz' = diag(4(.125), .4) = diag(.5, .4);  C = diag(1, .5)
+#     :92     Prr jxr' = [.1 0; 0 .1; -.2 0]
+#     P_A = [.1 0 0 .1 0; 0 .1 0 0 .1; 0 0 .1 -.2 0; .1 0 -.2 1 0; 0 .1 0 0 .5],  x_A = [0 0 90 | 0 2],  s = [5]
+#   correction of landmark 1 with z = [2.5 10], R = diag(.1, .125):
+#     :125-130  delta = (0, 2), q = 4, z_k = [2; wrapTo360(atan2d(2,0) - 90)] = [2; 0]
+#     :137-138  H_s = (1/4)[0 -4 0 0 4; 2 0 -4 -2 0] = [0 -1 0 0 1; .5 0 -1 -.5 0]
+#     G = H P_A:  row 1 = -P(2,:) + P(5,:) = [0 0 0 0 .4];  row 2 = .5 P(1,:) - P(3,:) - .5 P(4,:) = [0 0 0 -.25 0]
+#               (the robot columns cancel ONLY with P(1:3,new) = Prr jxr' as written: .5(.1) - .5(.1), -.1 - .5(-.2))
+#     :141      phi = diag(.4 + .1, .125 + .125) = diag(.5, .25),  K = G' phi^-1 = [0 0; 0 0; 0 0; 0 -1; .8 0]
+#     :144      nu = [.5; 10] (bearing innovation un-wrapped, H's bearing row in rad/m against degrees: -1 * 10 on the landmark's x)
+#               x+ = [0 0 90 | -10 2.4]
+#     :145      P+ = P_A - K G:  P44 = 1 - .25 = .75,  P55 = .5 - .32 = .18, nothing else moves
+K15_X = np.array([0.0, 0, 90])
+K15_P = np.diag([.1, .1, .1])
+K15_APPEND = dict(u=[2.0, 90.0], R=np.diag([.4, .125]), pos=[0.0, 2.0], sig=5.0)
+K15_X_A = np.array([0.0, 0, 90, 0, 2])
+K15_P_A = np.array([
+    [.1, 0, 0, .1, 0],
+    [0, .1, 0, 0, .1],
+    [0, 0, .1, -.2, 0],
+    [.1, 0, -.2, 1, 0],
+    [0, .1, 0, 0, .5]])
+K15_Z, K15_R = np.array([2.5, 10.0]), np.diag([.1, .125])
+K15_X_OUT = np.array([0.0, 0, 90, -10, 2.4])
+K15_P_OUT = K15_P_A.copy()
+K15_P_OUT[3, 3], K15_P_OUT[4, 4] = .75, .18

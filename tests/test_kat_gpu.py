@@ -206,3 +206,25 @@ def test_kat14_known_correspondence_dispatch_quirks_on_the_gpu(tile, batch):
     np.testing.assert_allclose(h.x, K.K14B_X_OUT, rtol=0, atol=5e-16)
     np.testing.assert_allclose(h.P, K.K14B_P_OUT, rtol=0, atol=2e-13)
     np.testing.assert_array_equal(h.s, K.K14B_S_OUT)
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+def test_kat15_append_then_correct_the_appended_landmark_on_the_gpu(tile, batch):
+    """KAT-15 (tests/kat_cases.py): append at heading 90 onto an empty map, then the correction of that landmark; with a predict of zero
+    motion in front of the append the launch that carries the predict out is the append's own (k_append<.., kPredict>)."""
+    from ekf_slam_amd import Engine
+    a = K.K15_APPEND
+    for zero_motion_first in (False, True):
+        e = Engine(capacity=4, tile=tile, batch=batch)
+        e.set_state(K.K15_X, K.K15_P, [])
+        if zero_motion_first:
+            e.set_params(C=0.0)                              # Q = (W C) W' = 0 and F = I for u = [0 0]: the predict changes nothing
+            e.predict([0.0, 0.0])
+        e.append(a["u"], a["R"], a["pos"], a["sig"])
+        np.testing.assert_array_equal(e.get_x(), K.K15_X_A)
+        np.testing.assert_allclose(e.get_P(), K.K15_P_A, rtol=0, atol=2e-16)
+        e.correct(K.K15_Z, K.K15_R, 0)
+        np.testing.assert_allclose(e.get_x(), K.K15_X_OUT, rtol=0, atol=2e-15)
+        np.testing.assert_allclose(e.get_P(), K.K15_P_OUT, rtol=0, atol=2e-16)
+        np.testing.assert_array_equal(e.get_s(), [5.0])
+        e.close()

@@ -307,3 +307,18 @@ def test_trace_non_increasing_across_correction(oracle_lib):
     before = np.trace(st.P)
     st.correct(z, np.diag([0.03, 225.0]), 4)
     assert np.trace(st.P) <= before + 1e-12
+
+
+def test_kat15_append_then_correct_the_appended_landmark_by_hand(oracle_lib):
+    """EKF_SLAM.m:67-98 then :124-145 (KAT-15): the correction reads the cross-covariances the append wrote; the robot columns of
+    G = H P cancel only if P(1:3,new) = Prr jxr' carries the signs the reference gives it."""
+    a = K.K15_APPEND
+    for name, e, correct in _both():
+        _load(e, K.K15_X, K.K15_P, [])
+        e.append(a["u"], a["R"], a["pos"], a["sig"])
+        np.testing.assert_array_equal(e.x, K.K15_X_A, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K15_P_A, rtol=0, atol=2e-16, err_msg=name)
+        correct(K.K15_Z, K.K15_R, 1)
+        np.testing.assert_allclose(e.x, K.K15_X_OUT, rtol=0, atol=2e-15, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K15_P_OUT, rtol=0, atol=2e-16, err_msg=name)
+        np.testing.assert_array_equal(np.asarray(e.s, dtype=float), [5.0])
