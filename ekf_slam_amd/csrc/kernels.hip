@@ -2023,13 +2023,14 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 }
 
 // "F32 mixed precision with F64 innovation solve" (BASELINE.json configs[4]; cfg.pass_arith = EKF_ARITH_F32): the same pass over float tiles
-// with the rank-2m product ON THE F32 MATRIX PIPE -- v_mfma_f32_16x16x4_f32, twice the f64 instruction's rate on gfx950 (256 against 128
-// flop/clk/CU), a float accumulator per element (the tile's own 16 bytes per lane and row: no widening, half the registers).  -K and G are
-// rounded to float when they are staged; everything that DECIDES anything -- innovation, S, its inverse, K, the state, the robot block, the
-// strip, the landmarks' diagonal blocks (DevState::diag) -- stays in F64 in the gather kernel.  What changes against the F64-arithmetic pass is
-// the rounding of the off-diagonal landmark entries: one float rounding per rank-1 term instead of one per pass (tolerance: DESIGN.md 5).
-// Geometry as k_flush_mfma's (a workgroup = 64 rows x 128 columns, a wavefront 16 rows x 128 columns = 8 accumulator blocks); the f32
-// instruction's result layout differs from the f64 one's: lane (lr, lc) register r is row 4 lr + r (f64: lr + 4 r) of column block lc.
+// with the rank-2m product ON THE F32 MATRIX PIPE -- v_mfma_f32_16x16x4_f32, measured at three times the f64 instruction's rate on this chip
+// (scripts/probes/mfma_f32_rate.hip).  The operands are the float copies of the pending pairs that the gather writes beside the F64 ones
+// (DevState::Gp32 / Kp32); the accumulators hold only the pass's update -sum_i K_i G_i, summed in float from zero, and the float tile value is
+// added to it ONCE (see below): one rounding at the entry's magnitude per pass, as the F64-arithmetic pass has.  Everything that DECIDES
+// anything -- innovation, S, its inverse, K, the state, the robot block, the strip, the landmarks' diagonal blocks (DevState::diag) -- stays in
+// F64 in the gather kernel (tolerance: DESIGN.md 5).
+// Geometry: a workgroup = 64 kRG rows x 128 columns, a wavefront kRG x 16 rows x 128 columns = 8 kRG accumulator blocks; the f32 instruction's
+// result layout differs from the f64 one's: lane (lr, lc) register r is row 4 lr + r (f64: lr + 4 r) of column block lc.
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 template <int T, int kChunk, int kRG, int kWpe, bool kEarly = false>
