@@ -110,12 +110,13 @@ typedef struct ekf_config {
                                     world == 1 -- how that path is exercised and timed on a single GPU */
     int32_t pass_arith;          /* EKF_ARITH_*: arithmetic of the pass over P.  EKF_ARITH_F32 ("F32 mixed precision with F64 innovation
                                     solve", BASELINE.json configs[4]) needs storage = EKF_STORE_F32 and tile = 256 (EKF_ERR_INVALID_ARG
-                                    otherwise): the pending pairs' K and G are rounded to float and the rank-2m product is accumulated in
-                                    float on the f32 matrix pipe (three times the f64 pipe's measured rate); passes of one or two pairs are purely
-                                    HBM-bound and keep the F64-arithmetic kernel.  The
-                                    innovation, S, K, x, the robot block, the strip and the landmarks' 2x2 diagonal blocks are F64 as
-                                    always.  Off-diagonal landmark entries then see one float rounding per rank-1 term instead of one
-                                    per pass; measured against the F64 engine: DESIGN.md section 5. */
+                                    otherwise): the pass's update -sum K_i G_i is formed from float copies of the pending pairs and
+                                    summed in float on the f32 matrix pipe (three times the f64 pipe's measured rate), then added to the
+                                    float tile value ONCE -- an entry still sees one rounding at its own magnitude per pass, as with
+                                    EKF_ARITH_F64.  Passes of one or two pairs are purely HBM-bound and keep the F64-arithmetic kernel.
+                                    The innovation, S, K, x, the robot block, the strip and the landmarks' 2x2 diagonal blocks are F64 as
+                                    always.  Costs pcap x 4 N floats for the copies.  Measured against the F64 engine: DESIGN.md section 5
+                                    (the whole configs[4] workload, 40 000 -> 50 000 landmarks: 2e-8). */
     int32_t reserved[2];
 } ekf_config;
 
