@@ -89,8 +89,12 @@ struct ekf_handle {
     // (signature, landmark) sorted by signature: the signature-only decision of a large map looks at the few landmarks whose
     // signature lies within the threshold of z(3) instead of all N (the mirror's O(N) scan per observation would pace the host
     // at ~10 us per row from 10 k landmarks on).  Rebuilt lazily after bulk changes, kept up to date by appends.
-    mutable std::vector<std::pair<double, int64_t>> s_sorted;
+    // Appends go to an unsorted TAIL that every query scans linearly and that is merged into the sorted part once it holds
+    // kSortedTail entries (an insertion into the sorted vector moved ~0.8 MB per append at 50 k landmarks, on the host's
+    // critical path of a streaming-append step).
+    mutable std::vector<std::pair<double, int64_t>> s_sorted, s_tail;
     mutable bool s_sorted_ok = false;
+    static constexpr size_t kSortedTail = 2048;
     // run-ahead throttle: the host may queue at most ~2*kThrottle update-steps ahead of the device.  Measured: the
     // first time ~150-190 launches are outstanding on a stream, one launch call blocks for 35-45 ms (the runtime
     // grows a per-queue pool); with the run-ahead bounded below that the stall never happens.
@@ -201,6 +205,15 @@ hipError_t dalloc(ekf_handle *h, Tp **p, size_t count) {
 }
 
 inline int64_t n_mm(const ekf_handle *h) { return 2 * h->N; }
+
+// Pair slots must read as zero beyond the active columns (the pass kernels read whole tile-wide slices of K and G): whenever the
+// map shrinks or the state is replaced, every ring is cleared -- the F64 pairs AND their float copies (cfg.pass_arith = EKF_ARITH_F32).
+hipError_t clear_pairs(ekf_handle *h) {
+    const size_t elems = (size_t)h->st.pair_stride * h->st.pcap * 2;       // G ring, then K ring: one allocation each
+    hipError_t e = hipMemsetAsync(h->st.Gp, 0, elems * 8, h->stream);
+    if (e == hipSuccess && h->st.Gp32) e = hipMemsetAsync(h->st.Gp32, 0, elems * 4, h->stream);
+    return e;
+}
 inline size_t elt_size(const ekf_handle *h) { return h->storage == EKF_STORE_F64 ? 8 : 4; }
 
 int32_t use_device(ekf_handle *h) {
@@ -507,10 +520,8 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     }
     if ((int64_t)h->s_host.size() > h->N) { h->s_host.resize((size_t)h->N); h->s_sorted_ok = false; }
     h->s_host.push_back(signature);
-    if (h->s_sorted_ok && signature == signature) {       // keep the index sorted by (signature, landmark); NaN never matches anything
-        const std::pair<double, int64_t> e(signature, h->N);
-        h->s_sorted.insert(std::upper_bound(h->s_sorted.begin(), h->s_sorted.end(), e), e);
-    }
+    if (h->s_sorted_ok && signature == signature)         // the index learns of it through its unsorted tail; NaN never matches anything
+        h->s_tail.emplace_back(signature, h->N);
     h->N += 1;
     h->pf_valid = false;
     h->nx_valid = false;
@@ -862,21 +873,30 @@ void associate_signature_only(const ekf_handle *h, double z3, int32_t *is_new, i
     // large map only the landmarks inside that window of the sorted index are evaluated -- with the very same expression
     const double w = (inv_cost > 0.0 && thresh >= 0.0) ? sqrt(thresh / inv_cost) * (1.0 + 1e-9) + 1e-300 : INFINITY;
     if (N >= 256 && w < INFINITY && z3 == z3) {
-        if (!h->s_sorted_ok || (int64_t)h->s_sorted.size() > N) {
+        if (!h->s_sorted_ok || (int64_t)(h->s_sorted.size() + h->s_tail.size()) > N) {
             h->s_sorted.clear();
+            h->s_tail.clear();
             h->s_sorted.reserve((size_t)N);
             for (int64_t k = 0; k < N; ++k) if (h->s_host[(size_t)k] == h->s_host[(size_t)k]) h->s_sorted.emplace_back(h->s_host[(size_t)k], k);
             std::sort(h->s_sorted.begin(), h->s_sorted.end());
             h->s_sorted_ok = true;
+        } else if (h->s_tail.size() >= ekf_handle::kSortedTail) {
+            const size_t mid = h->s_sorted.size();
+            std::sort(h->s_tail.begin(), h->s_tail.end());
+            h->s_sorted.insert(h->s_sorted.end(), h->s_tail.begin(), h->s_tail.end());
+            std::inplace_merge(h->s_sorted.begin(), h->s_sorted.begin() + (ptrdiff_t)mid, h->s_sorted.end());
+            h->s_tail.clear();
         }
         const auto lo = std::lower_bound(h->s_sorted.begin(), h->s_sorted.end(), std::pair<double, int64_t>(z3 - w, -1));
         const auto hi = std::upper_bound(lo, h->s_sorted.end(), std::pair<double, int64_t>(z3 + w, INT64_MAX));
         if (hi - lo < N / 2) {
-            for (auto it = lo; it != hi; ++it) {
-                const double d = z3 - it->first;
+            auto consider = [&](double sk, int64_t k) {
+                const double d = z3 - sk;
                 const double ll = d * inv_cost * d;
-                if (ll <= thresh && (ll < best || (ll == best && it->second < *idx))) { *is_new = 0; best = ll; *idx = it->second; }
-            }
+                if (ll <= thresh && (ll < best || (ll == best && k < *idx))) { *is_new = 0; best = ll; *idx = k; }
+            };
+            for (auto it = lo; it != hi; ++it) consider(it->first, it->second);
+            for (const auto &e : h->s_tail) consider(e.first, e.second);     // landmarks appended since the last merge
             return;
         }
     }
@@ -1434,6 +1454,7 @@ int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv) {
     REQUIRE(h, h->sharded && !h->pending, EKF_ERR_STATE, "exchange_set_buffers: not sharded, or a correction is pending");
     h->send = send ? (double *)send : h->own_send;
     h->recv = recv ? (double *)recv : h->own_recv;
+    h->nx_valid = false;       // corr_send() may point elsewhere now: a hinted extraction sits in the old area
     return EKF_OK;
 }
 
@@ -1493,6 +1514,7 @@ int32_t ekf_comm_init(ekf_handle *h, const ekf_comm_id *id) {
     const int r = g_rccl.CommInitRank(&comm, h->cfg.world, *id, h->cfg.rank);
     if (r != 0) return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r));
     h->comm = comm;
+    h->nx_valid = false;       // with a communicator the row-panel goes straight into the receive area (corr_send)
     return EKF_OK;
 }
 
@@ -1535,10 +1557,7 @@ int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n) {
     if (rc) return rc;
     rc = flush_pending(h);     // pending pairs belong to the old state
     if (rc) return rc;
-    if ((n - 3) / 2 < h->N) {  // shrinking the map: pair slots must read as zero beyond the active columns
-        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-    }
+    if ((n - 3) / 2 < h->N) HIPCHK(h, clear_pairs(h));      // shrinking the map
     h->N = (n - 3) / 2;
     h->pf_valid = false;       // a prefetch belongs to the state it was taken from
     h->nx_valid = false;
@@ -1659,10 +1678,7 @@ int32_t ekf_load_lowrank_state(ekf_handle *h, int64_t N, const double *x, const 
     int32_t rc = enter(h);
     if (rc) return rc;
     const int64_t n = 3 + 2 * N;
-    if (N < h->N) {
-        HIPCHK(h, hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream));
-    }
+    if (N < h->N) HIPCHK(h, clear_pairs(h));
     h->N = N;
     h->s_host.assign(s, s + N);
     h->s_sorted_ok = false;
@@ -1762,8 +1778,11 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     // every exit below goes through here: the file is closed and the staging buffer released whatever happened
     auto done = [&](int32_t status) { if (stage) hipHostFree(stage); fclose(f); return status; };
     CkptHeader hd;
-    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, "EKFSLAM2", 8) != 0)
-        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM2 file"));
+    if (fread(&hd, sizeof hd, 1, f) != 1) return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM2 file"));
+    if (memcmp(hd.magic, "EKFSLAM1", 8) == 0)
+        return done(fail(h, EKF_ERR_STATE, "checkpoint_load: EKFSLAM1 file -- that format (no section for the landmarks' live diagonal "
+                                           "blocks) is no longer read; re-save the state with this library (INTEGRATION.md, checkpoints)"));
+    if (memcmp(hd.magic, "EKFSLAM2", 8) != 0) return done(fail(h, EKF_ERR_STATE, "checkpoint_load: not an EKFSLAM2 file"));
     if (hd.tile != h->T || hd.storage != h->storage || hd.world != h->cfg.world || hd.rank != h->cfg.rank || hd.N < 0 || hd.N > h->cap)
         return done(fail(h, EKF_ERR_STATE, "checkpoint_load: tile edge, storage, shard or capacity do not match this handle"));
     const int64_t nmm = 2 * hd.N, nt = ekf_tiles_for(nmm, h->T);
@@ -1781,8 +1800,7 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path) {
     rc = retire_inflight(h);
     if (rc) return done(rc);
     h->npend = 0; h->pstart = 0; h->pf_valid = false; h->nx_valid = false; h->have_pp = false;
-    hipError_t e = hipMemsetAsync(h->st.Gp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->st.Kp, 0, (size_t)h->st.pair_stride * h->st.pcap * 8, h->stream);
+    hipError_t e = clear_pairs(h);
     if (e != hipSuccess) return done(fail(h, EKF_ERR_HIP, "checkpoint_load: clearing the pending pairs", e));
     std::vector<double> shost((size_t)hd.N);
     rc = stream_in(h, f, h->st.x[h->cur], (size_t)(3 + nmm) * 8, stage, stage_bytes);

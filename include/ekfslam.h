@@ -256,10 +256,11 @@ int32_t ekf_P_digest(ekf_handle *h, double out[3]);
 int32_t ekf_device_bytes(ekf_handle *h, int64_t *bytes);
 
 /* ---- checkpoint (the reference has none; its whole state is the four properties x, P, Q, s, EKF_SLAM.m:6-9) ----
- * Binary file: 64-byte header (magic "EKFSLAM1", N, tile, storage, world, rank), then x, s, the robot block, the
- * robot/landmark strip and this handle's tiles of the active tile rows, bit for bit (pending pairs are flushed first).
- * Loading needs a handle with the same tile edge, storage type and shard (rank/world) and capacity >= N; a sharded
- * filter is one file per shard. */
+ * Binary file: 64-byte header (magic "EKFSLAM2", N, tile, storage, world, rank), then x, s, the robot block, the
+ * robot/landmark strip, the landmarks' live F64 diagonal blocks (3 doubles each) and this handle's tiles of the active
+ * tile rows, bit for bit (pending pairs are flushed first).  Loading needs a handle with the same tile edge, storage type
+ * and shard (rank/world) and capacity >= N; a sharded filter is one file per shard.  Files with the magic "EKFSLAM1"
+ * (no diagonal-block section) are rejected with EKF_ERR_STATE and a message that says so: there is no migration. */
 int32_t ekf_checkpoint_save(ekf_handle *h, const char *path);
 int32_t ekf_checkpoint_load(ekf_handle *h, const char *path);
 

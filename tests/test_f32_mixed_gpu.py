@@ -129,3 +129,39 @@ def test_f32_arithmetic_unknown_correspondence_device_loop(oracle_lib):
     np.testing.assert_array_equal(dev.x, host.x)
     np.testing.assert_array_equal(dev.P, host.P)
     assert rel_err(dev.x, ref.x) < TOL_X and rel_err(dev.P, ref.P) < TOL_P
+
+
+@pytest.mark.parametrize("how", ["set_state", "lowrank", "checkpoint"])
+def test_a_reused_handle_leaves_no_stale_float_pairs_beyond_a_smaller_map(how, tmp_path):
+    """The float copies of the pending pairs (DevState::Gp32 / Kp32) must read as zero beyond the active columns, like the F64 pairs: a
+    handle that ran at N1 landmarks and is then loaded with a smaller state N0 < N1, streams appends across a 256-column tile edge with
+    several pairs pending -- its pass reads whole tile-wide slices of K and G, i.e. slots' columns beyond the map as it was when the slot
+    was written.  Equal bit for bit to a fresh handle given the same state and steps."""
+    from ekf_slam_amd import Engine
+    N1, N0, batch = 700, 380, 6                              # 760 rows: the appends cross the tile edge at 768 rows
+    cap = N1 + 8
+    used = Engine(capacity=cap, storage="f32_mixed", batch=batch)
+    fresh = Engine(capacity=cap, storage="f32_mixed", batch=batch)
+    x1, P1, s1 = _state(N1, 5)
+    used.set_state(x1, P1, s1)
+    _run([used], None, 2 * batch + 3, 3)                     # every ring slot written at 1 400 columns, three pairs left pending
+    rng = np.random.default_rng(8)
+    n0 = 3 + 2 * N0
+    x0 = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-20, 20, size=2 * N0)])
+    d0, U0 = rng.uniform(0.01, 0.1, size=n0), rng.normal(0, 0.05, size=(n0, 6))
+    s0 = np.arange(1, N0 + 1.0)
+    if how == "set_state":
+        P0 = np.diag(d0) + U0 @ U0.T
+        used.set_state(x0, P0, s0); fresh.set_state(x0, P0, s0)
+    elif how == "lowrank":
+        used.load_lowrank_state(x0, s0, d0, U0); fresh.load_lowrank_state(x0, s0, d0, U0)
+    else:
+        fresh.load_lowrank_state(x0, s0, d0, U0)
+        fresh.checkpoint_save(tmp_path / "n0.ckpt")
+        used.checkpoint_load(tmp_path / "n0.ckpt")
+    _run([used, fresh], None, 3 * batch + 1, 21, appends=(1, 2, 3, 4, 5, 7, 8, 9))     # 388 landmarks = 776 rows > 768
+    assert used.N == fresh.N == N0 + 8 and 2 * used.N > 768
+    used.flush(); fresh.flush()
+    assert used.downdate_kernel_name()[0].startswith("k_flush_mfma")
+    np.testing.assert_array_equal(used.get_x(), fresh.get_x())
+    np.testing.assert_array_equal(used.get_P(), fresh.get_P())
