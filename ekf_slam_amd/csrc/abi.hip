@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "device_math.h"
+#include "flush32_pipe.h"
 #include "kernels.h"
 #include "layout.h"
 
@@ -110,6 +111,10 @@ struct ekf_handle {
     // inside its own 4 MiB L2); stream x is work_xcd[x * xcd_len .. ), padded with (-1,-1)
     int2 *d_work_xcd = nullptr;
     int64_t xcd_len = 0;
+    // cfg.pass_arith = EKF_ARITH_F32: the strip form of the pass (flush32_pipe.h) -- its work list, the page of zeros, the dump area
+    PassAux aux = { nullptr, 0, nullptr, nullptr, 0 };
+    int4 *d_segs = nullptr;
+    int64_t segs_cap = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
     AssocDecision *h_decision_dev = nullptr;   // device-side address of the mapped h_decision (k_assoc_merge, the sharded path, writes it)
     int *d_ticket = nullptr;                   // k_associate's last-workgroup ticket (device-side consumers only)
@@ -283,6 +288,17 @@ int32_t refresh_work(ekf_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     h->xcd_len = (int64_t)len;
+    if (h->d_segs) {                                  // the strip work list of the same tiles
+        std::vector<int4> sg;
+        const int64_t nsegs = build_strip_segments(h->st.tm, nt, sg);
+        REQUIRE(h, (int64_t)sg.size() <= h->segs_cap, EKF_ERR_STATE, "strip work list overflow");
+        if (!sg.empty()) {
+            HIPCHK(h, hipMemcpyAsync(h->d_segs, sg.data(), sg.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        h->aux.segs = h->d_segs;
+        h->aux.nsegs = nsegs;
+    }
     return EKF_OK;
 }
 
@@ -369,7 +385,8 @@ int32_t flush_pending(ekf_handle *h) {
         }
         TimedLaunch tl(h, EKF_KERNEL_DOWNDATE);
         HIPCHK(h, launch_downdate(h->st, h->st.tiles, h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart, h->npend,
-                                  h->storage, h->grid_cap, h->stream, h->dd_kernel, nx.j >= 0 ? &nx : nullptr, &extracted, h->cfg.pass_arith));
+                                  h->storage, h->grid_cap, h->stream, h->dd_kernel, nx.j >= 0 ? &nx : nullptr, &extracted, h->cfg.pass_arith,
+                                  h->d_segs ? &h->aux : nullptr));
         h->dd_pairs = h->npend;
     }
     h->npend = 0;
@@ -409,7 +426,8 @@ int32_t batch_complete(ekf_handle *h) {
         }
         next_pass_direction(h);
         HIPCHK(h, launch_downdate(h->st, h->tilebuf[h->base ^ 1], h->d_work, h->nwork, h->d_work_xcd, h->xcd_len, h->pstart,
-                                  h->npend, h->storage, h->grid_cap, h->flush_stream, h->dd_kernel, nullptr, nullptr, h->cfg.pass_arith));
+                                  h->npend, h->storage, h->grid_cap, h->flush_stream, h->dd_kernel, nullptr, nullptr, h->cfg.pass_arith,
+                                  h->d_segs ? &h->aux : nullptr));
         h->dd_pairs = h->npend;
         if (stop) HIPCHK(h, hipEventRecord(stop, h->flush_stream));
     }
@@ -1072,6 +1090,25 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->pass_arith == EKF_ARITH_F32) {
         HIPCHK(h, dalloc(h, &h->st.Gp32, (size_t)(2 * ldm) * h->st.pcap * 2));
         h->st.Kp32 = h->st.Gp32 + (size_t)(2 * ldm) * h->st.pcap;
+        // the strip form of the pass: work list (every item once + one padded segment per 128-row slab and column range at most), zeros, dump
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
+        h->aux.grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        h->aux.grid -= h->aux.grid % 8;                                   // (block b walks XCD stream b & 7)
+        if (h->aux.grid < 8) h->aux.grid = 8;
+        const int64_t ranges = (2 * nt_cap + ekf_pipe32::kSeg * world - 1) / (ekf_pipe32::kSeg * world);
+        h->segs_cap = 4 * slots + (2 * nt_cap * ranges + 8) * ekf_pipe32::kSeg;
+        HIPCHK(h, dalloc(h, &h->d_segs, (size_t)h->segs_cap));
+        float *zeros = nullptr, *dump = nullptr;
+        HIPCHK(h, dalloc(h, &zeros, (size_t)ekf_pipe32::kZeroFloats));
+        {
+            float z[ekf_pipe32::kZeroFloats];
+            for (int i = 0; i < ekf_pipe32::kZeroFloats; ++i) z[i] = i < 256 ? -0.0f : 0.0f;
+            HIPCHK(h, hipMemcpy(zeros, z, sizeof z, hipMemcpyHostToDevice));
+        }
+        HIPCHK(h, dalloc(h, &dump, (size_t)h->aux.grid * ekf_pipe32::kDumpFloats));
+        h->aux.zeros = zeros;
+        h->aux.dump = dump;
     }
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));

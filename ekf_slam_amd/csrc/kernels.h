@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "layout.h"
 
 // Tuning switches.  The PRODUCT library compiles every one of them to its default constant: no environment variable changes
@@ -31,8 +33,9 @@ struct DevState {
     // (pstart + i) mod pcap, i = 0 .. npend-1, oldest first.
     double *Gp;           // pending G pairs, then (same allocation) ...
     double *Kp;           // ... the pending K pairs: Kp = Gp + pcap * pair_stride (k_gather relies on a 32-bit offset between them)
-    float  *Gp32;         // cfg.pass_arith = EKF_ARITH_F32 only (nullptr otherwise): float copies of the same pairs, same slots and interleaving,
-    float  *Kp32;         // written by the gather beside the F64 ones -- what the F32-arithmetic pass reads (half the operand bytes)
+    float  *Gp32;         // cfg.pass_arith = EKF_ARITH_F32 only (nullptr otherwise): float copies of the same pairs in the same slots, written by the
+    float  *Kp32;         // gather beside the F64 ones for the F32-arithmetic pass (half the operand bytes) -- PLANAR (slot s: plane x = ldm floats, then
+                          // plane y) and, for K, NEGATED (-(float)K, exact): the pass's LDS-DMA pieces are plain copies (flush32_pipe.h)
     int64_t pair_stride;   // 2 * ldm
     int32_t pcap;          // slots in the ring
     double *small;     // 32: Gr[2][3] (0..5), Kr[3][2] (6..11), Q[9] (12..20)
@@ -172,9 +175,20 @@ hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const
 // of launch_rowpanel) from the updated entries; *extracted tells whether the instance that was launched did it (one pair per
 // launch, wavefront-per-row tile shapes only)
 struct NextRow { int64_t j; double *send; };
+// what the strip form of the F32-arithmetic pass needs besides the tiles and the pairs (flush32_pipe.h; nullptr: that form is not used)
+struct PassAux {
+    const int4 *segs;      // strip work list: nsegs segments of ekf_pipe32::kSeg entries (strip_entry), 8 interleaved per-XCD streams
+    int64_t nsegs;         // a multiple of 8
+    const float *zeros;    // kZeroFloats floats: [0, 256) -0.0f, [256, 512) +0.0f
+    float *dump;           // kDumpFloats floats per workgroup of the pass's grid
+    int grid;              // workgroups the dump area was sized for (one per CU)
+};
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx = nullptr,
-                           bool *extracted = nullptr, int arith = 0);
+                           bool *extracted = nullptr, int arith = 0, const PassAux *aux = nullptr);
+// strip work list of the owned lower-triangle tiles of nt tile rows (host side; entries for flush32_pipe.h::k_flush_strip32): returns
+// the segment count (a multiple of 8) and fills `out` with nsegs * kSeg entries
+int64_t build_strip_segments(const TileMap &tm, int64_t nt, std::vector<int4> &out);
 // pos_cost / sig_cost: device arrays of N or nullptr; partial: device scratch of >= ceil(N/kAssocBlock) entries; ticket: a
 // device int, zero between launches (the last workgroup to finish reduces the partials and resets it: one launch, no
 // finishing kernel); decision: device copy.  host_partials != nullptr (mapped host memory, one entry per workgroup): NO cross-workgroup

@@ -15,14 +15,16 @@
 //   k_associate  per-landmark phi_k, Mahalanobis + signature     Correspondence.m:49-87
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
 #include "device_math.h"
+#include "flush32_mfma.h"     // kBlock, ring_slot, k_flush_mfma32
+#include "flush32_pipe.h"     // k_flush_pipe32
 
 namespace {
 
-constexpr int kBlock = 256;
 
 // ---------------------------------------------------------------------------------------------------
 // element access
@@ -66,7 +68,6 @@ __device__ __forceinline__ double rank2_apply(double v, double2 k, double2 g) {
     return fma(-k.y, g.y, fma(-k.x, g.x, v));       // v - K(r,1) G(1,c) - K(r,2) G(2,c): two FMAs, fixed order
 }
 
-__device__ __forceinline__ int ring_slot(int pstart, int i, int pcap) { const int s = pstart + i; return s >= pcap ? s - pcap : s; }
 
 // full-state element P(r,c), r,c in [0, 3+n_mm)
 template <typename TS>
@@ -1077,9 +1078,9 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         if (!kFused) {
             Gout[c] = make_double2(g[0], g[1]);
             Kout[c] = make_double2(k0, k1);
-            if (st.Gp32) {                                          // uniform: the F32-arithmetic pass reads float copies
-                reinterpret_cast<float2 *>(st.Gp32 + out_off)[c] = make_float2((float)g[0], (float)g[1]);
-                reinterpret_cast<float2 *>(st.Kp32 + out_off)[c] = make_float2((float)k0, (float)k1);
+            if (st.Gp32) {                                          // uniform: the F32-arithmetic pass reads float copies, planar, K negated
+                st.Gp32[out_off + c] = (float)g[0]; st.Gp32[out_off + ldm + c] = (float)g[1];
+                st.Kp32[out_off + c] = -(float)k0; st.Kp32[out_off + ldm + c] = -(float)k1;
             }
         }
         xn = xc + (k0 * sol.nu[0] + k1 * sol.nu[1]);
@@ -1096,8 +1097,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         Gout[c] = make_double2(0.0, 0.0);
         Kout[c] = make_double2(0.0, 0.0);
         if (st.Gp32) {
-            reinterpret_cast<float2 *>(st.Gp32 + out_off)[c] = make_float2(0.0f, 0.0f);
-            reinterpret_cast<float2 *>(st.Kp32 + out_off)[c] = make_float2(0.0f, 0.0f);
+            st.Gp32[out_off + c] = 0.0f; st.Gp32[out_off + ldm + c] = 0.0f;
+            st.Kp32[out_off + c] = -0.0f; st.Kp32[out_off + ldm + c] = -0.0f;
         }
     }
     // (4b) this correction's pair on the diagonal blocks, at once: P(I - K H) restricted to each landmark's own 2x2 block, rank2_apply in
@@ -2022,158 +2023,6 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
     }
 }
 
-// "F32 mixed precision with F64 innovation solve" (BASELINE.json configs[4]; cfg.pass_arith = EKF_ARITH_F32): the same pass over float tiles
-// with the rank-2m product ON THE F32 MATRIX PIPE -- v_mfma_f32_16x16x4_f32, measured at three times the f64 instruction's rate on this chip
-// (scripts/probes/mfma_f32_rate.hip).  The operands are the float copies of the pending pairs that the gather writes beside the F64 ones
-// (DevState::Gp32 / Kp32); the accumulators hold only the pass's update -sum_i K_i G_i, summed in float from zero, and the float tile value is
-// added to it ONCE (see below): one rounding at the entry's magnitude per pass, as the F64-arithmetic pass has.  Everything that DECIDES
-// anything -- innovation, S, its inverse, K, the state, the robot block, the strip, the landmarks' diagonal blocks (DevState::diag) -- stays in
-// F64 in the gather kernel (tolerance: DESIGN.md 5).
-// Geometry: a workgroup = 64 kRG rows x 128 columns, a wavefront kRG x 16 rows x 128 columns = 8 kRG accumulator blocks; the f32 instruction's
-// result layout differs from the f64 one's: lane (lr, lc) register r is row 4 lr + r (f64: lr + 4 r) of column block lc.
-typedef float f4_t __attribute__((ext_vector_type(4)));
-
-template <int T, int kChunk, int kRG, int kWpe, bool kEarly = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
-void k_flush_mfma32(const float *__restrict__ tiles, float *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
-                    const float *__restrict__ Kp, const float *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
-                    int npairs, TileMap tm) {
-    // kRG: 16-row groups per wavefront -- a workgroup owns 64 kRG rows x 128 columns (kRG = 2: twice the bytes in flight per workgroup and
-    // one read of G from LDS for 16 instead of 8 MFMAs).  Production: kChunk = 4, kRG = 2, four wavefronts per SIMD (profiles/round3_tuning.md 36).
-    constexpr int kRows = 64 * kRG, kCols = 128, kKPad = kRows + 16;
-    constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
-    static_assert(T % kCols == 0 && T % kRows == 0, "a wavefront owns 16 kRG rows x 128 columns");
-    static_assert(kChunk % 2 == 0 && (kChunk * kCols) % kBlock == 0 && (kChunk * kRows) % kBlock == 0, "bad chunk");
-    __shared__ __attribute__((aligned(16))) float Gs[2 * kChunk][kCols];
-    __shared__ float Ks[2 * kChunk][kKPad];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane >> 4, lc = lane & 15;
-    const int64_t nitems = 8 * nwork * kSubsPerTile;
-    for (int64_t it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int64_t vi = tm.reverse ? nwork * kSubsPerTile - 1 - (it >> 3) : (it >> 3);
-        const int64_t w = vi / kSubsPerTile;
-        const int sub = (int)(vi - w * kSubsPerTile);
-        const int2 ij = work[(it & 7) * nwork + w];
-        if (ij.x < 0) continue;
-        const int slab = sub / kColParts, cpart = sub - slab * kColParts;
-        const int row0 = slab * kRows + wave * 16;                    // row group rg: + 64 rg
-        const int64_t toff = tm.tile_offset(ij.x, ij.y) + (int64_t)(row0 + 4 * lr) * T + cpart * kCols + 4 * lc;
-        const float *__restrict__ tp = tiles + toff;
-        float *__restrict__ td = dst + toff;
-        // The accumulators start at ZERO and hold only the pass's update -sum_i K_i G_i; the tile value is added ONCE at the end (one float rounding
-        // per entry and pass, as the F64-arithmetic pass has).  Accumulating onto the tile value itself (the first version: tile loaded into the
-        // accumulators) rounds at the ENTRY's ulp after every rank-4 step: on the large entries (cross-covariances of appended landmarks, ~10) every
-        // small decrement was lost -- 7e-7 on sampled blocks, 4e-6 on the digests after configs[4]'s 10 000 update-steps (tests/test_full_size_gpu.py).
-        // The tile is requested after the last chunk, a row group's eight 16-byte pieces at a time (holding it in registers from the start spills
-        // at four wavefronts per SIMD; an early "touch" load + the late one moved the bytes twice: profiles/round3_tuning.md 36).
-        f4_t acc[kRG][2][4];                                          // [row group][16-byte group bp][column e in it][row r -> row0 + 64 rg + 4 lr + r]
-#pragma unroll
-        for (int rg = 0; rg < kRG; ++rg)
-#pragma unroll
-            for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[rg][bp][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
-        const int64_t gcol0 = (int64_t)ij.y * T + cpart * kCols;
-        const int64_t krow0 = (int64_t)ij.x * T + slab * kRows;
-        constexpr int kPerG = kChunk * kCols / kBlock, kPerK = kChunk * kRows / kBlock;
-        float2 tg[kPerG], tk[kPerK];                                  // (the pairs' float copies, written by the gather: DevState::Gp32 / Kp32)
-        auto fetch = [&](int c0, int cn) {
-#pragma unroll
-            for (int q = 0; q < kPerG; ++q) {
-                const int e = tid + q * kBlock, col = e & (kCols - 1);
-                const int i = (e >> 7) < cn ? (e >> 7) : cn - 1;
-                tg[q] = reinterpret_cast<const float2 *>(Gp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[gcol0 + col];
-            }
-#pragma unroll
-            for (int q = 0; q < kPerK; ++q) {
-                const int e = tid + q * kBlock, row = e & (kRows - 1);
-                const int i = (e / kRows) < cn ? (e / kRows) : cn - 1;
-                tk[q] = reinterpret_cast<const float2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
-            }
-        };
-        auto stage = [&](int cn) {                           // the fetched chunk de-interleaved to [k][col] / [k][row]
-#pragma unroll
-            for (int q = 0; q < kPerG; ++q) {
-                const int e = tid + q * kBlock, i = e >> 7, col = e & (kCols - 1);
-                if (i < cn) { Gs[2 * i][col] = tg[q].x; Gs[2 * i + 1][col] = tg[q].y; }
-                else if (i == cn) { Gs[2 * i][col] = 0.0f; Gs[2 * i + 1][col] = 0.0f; }       // pad of an odd count
-            }
-#pragma unroll
-            for (int q = 0; q < kPerK; ++q) {
-                const int e = tid + q * kBlock, i = e / kRows, row = e & (kRows - 1);
-                if (i < cn) { Ks[2 * i][row] = -tk[q].x; Ks[2 * i + 1][row] = -tk[q].y; }
-                else if (i == cn) { Ks[2 * i][row] = -0.0f; Ks[2 * i + 1][row] = -0.0f; }
-            }
-        };
-        auto apply = [&](int cn) {
-            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
-#pragma unroll 2
-            for (int ks = 0; ks < ksteps; ++ks) {
-                float a[kRG];
-#pragma unroll
-                for (int rg = 0; rg < kRG; ++rg) a[rg] = Ks[4 * ks + lr][64 * rg + wave * 16 + lc];
-                f4_t b[2];
-#pragma unroll
-                for (int bp = 0; bp < 2; ++bp) b[bp] = *reinterpret_cast<const f4_t *>(&Gs[4 * ks + lr][64 * bp + 4 * lc]);
-#pragma unroll
-                for (int rg = 0; rg < kRG; ++rg)
-#pragma unroll
-                    for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[rg][bp][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rg], b[bp][e], acc[rg][bp][e], 0, 0, 0);
-            }
-        };
-        auto count = [&](int c0) { return npairs - c0 < kChunk ? npairs - c0 : kChunk; };
-        fetch(0, count(0));
-        int c0 = 0;
-        for (; c0 + kChunk < npairs; c0 += kChunk) {
-            __syncthreads();                                          // everyone is done with the previous chunk
-            stage(count(c0));
-            __syncthreads();
-            fetch(c0 + kChunk, count(c0 + kChunk));
-            apply(count(c0));
-        }
-        __syncthreads();                                              // the last chunk, peeled: nothing is fetched behind it ...
-        stage(count(c0));
-        __syncthreads();
-        f4_t te[kEarly ? kRG : 1][2][4];                              // ... kEarly: the tile is requested HERE, in front of the last chunk's matrix work
-        if constexpr (kEarly) {
-#pragma unroll
-            for (int rg = 0; rg < kRG; ++rg)
-#pragma unroll
-                for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        te[rg][bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
-        }
-        apply(count(c0));
-#pragma unroll
-        for (int rg = 0; rg < kRG; ++rg) {
-            f4_t tl[2][4];
-#pragma unroll
-            for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if constexpr (kEarly) tl[bp][r] = te[rg][bp][r];
-                    else tl[bp][r] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(tp + (int64_t)(64 * rg + r) * T + 64 * bp));
-                }
-#pragma unroll
-            for (int bp = 0; bp < 2; ++bp)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    f4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[rg][bp][e][r];
-                    o += tl[bp][r];
-                    __builtin_nontemporal_store(o, reinterpret_cast<f4_t *>(td + (int64_t)(64 * rg + r) * T + 64 * bp));
-                }
-        }
-    }
-}
-
 // what was launched, for the measurement hooks (ekf_downdate_kernel_name): "k_xxx<double,128,4,false>"
 static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, int xcd) {
     if (!out) return;
@@ -2184,7 +2033,7 @@ static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, 
 // the MFMA flush for the (storage type, tile edge) pairs it exists for; false: not applicable, use the VALU kernels
 template <typename TS, int T>
 static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_xcd, int64_t xcd_len, int pstart, int npairs,
-                              int grid_cap, hipStream_t s, char *kname, int arith) {
+                              int grid_cap, hipStream_t s, char *kname, int arith, const PassAux *aux) {
     constexpr bool kHave = (sizeof(TS) == 8 && T == 128) || (sizeof(TS) == 4 && T == 256);
     if constexpr (kHave) {
         static const bool use_mfma = ekf_tune_int("EKF_FLUSH_MFMA", 1) != 0;
@@ -2197,6 +2046,20 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if constexpr (sizeof(TS) == 4) {
+            if (arith == 1 && npairs > 56 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0 && st.tm.world >= 1) {
+                // 57-64 pairs (eight stages of eight): the strip form -- -K resident in LDS along a row strip, loader wavefronts, one persistent
+                // workgroup per CU (flush32_pipe.h): 7.6-7.8 ms against 8.1-8.5 at 40 000 landmarks and 64 pairs, same bits
+                constexpr int kD = 3, kNL = 4;
+                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<kD, kNL, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   ekf_pipe32::lds_bytes_strip<kD>());
+                if (attr == hipSuccess) {
+                    hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<kD, kNL, 8>), dim3((unsigned)aux->grid), dim3(512 + 64 * kNL), ekf_pipe32::lds_bytes_strip<kD>(), s,
+                                       (const float *)st.tiles, (float *)dstv, aux->segs, aux->nsegs, (const float *)st.Kp32, (const float *)st.Gp32, st.pair_stride,
+                                       st.ldm, pstart, st.pcap, npairs, st.tm, aux->zeros, aux->dump, (unsigned long long *)nullptr);
+                    if (kname) snprintf(kname, 64, "k_flush_strip32<%d,%d,8>", kD, kNL);
+                    return true;
+                }
+            }
             if (arith == 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32: the f32 matrix pipe (one or two pairs: the pass is
                                                                       // purely HBM-bound and the F64-arithmetic kernel below streams it 5 % faster, 4.0 against 4.3 ms at 40 k)
 #define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
@@ -2263,10 +2126,10 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
 template <typename TS, int T, int kSlab>
 static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                      int64_t xcd_len, int pstart, int npairs, int grid_cap, hipStream_t s, char *kname,
-                                     const NextRow *nx, bool *extracted, int arith) {
+                                     const NextRow *nx, bool *extracted, int arith, const PassAux *aux) {
     constexpr int kLanes = T / Lane16<TS>::kCols;
     static const bool use_xcd = ekf_tune_int("EKF_FLUSH_XCD", 1) != 0;
-    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, arith)) return hipGetLastError();
+    if (use_xcd && launch_flush_mfma<TS, T>(st, dstv, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, arith, aux)) return hipGetLastError();
     if constexpr (kLanes == 64 || kLanes == 32) {
         if (npairs > 1 && use_xcd && work_xcd && xcd_len > 0) {
             int64_t grid = 8 * xcd_len * (T / kSlab);
@@ -2308,10 +2171,10 @@ static hipError_t launch_downdate_ts(const DevState &st, void *dstv, const int2 
 template <typename TS>
 static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *work, int64_t nwork, const int2 *work_xcd,
                                     int64_t xcd_len, int pstart, int npairs, int grid_cap, int slab, hipStream_t s, char *kname,
-                                    const NextRow *nx, bool *extracted, int arith) {
+                                    const NextRow *nx, bool *extracted, int arith, const PassAux *aux) {
     if (nwork <= 0 || npairs <= 0) return hipSuccess;
     constexpr bool kF32 = sizeof(TS) == 4;
-#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, nx, extracted, arith)
+#define EKF_DD(TT, SS) return launch_downdate_ts<TS, TT, SS>(st, dstv, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, s, kname, nx, extracted, arith, aux)
     if constexpr (kF32) {
         switch (st.tm.T) {
             case 16: EKF_DD(16, 16);
@@ -2338,13 +2201,41 @@ static hipError_t launch_downdate_t(const DevState &st, void *dstv, const int2 *
 
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx,
-                           bool *extracted, int arith) {
+                           bool *extracted, int arith, const PassAux *aux) {
     if (extracted) *extracted = false;
     static const int slab1 = ekf_tune_int("EKF_DOWNDATE_SLAB", 0);
     static const int slabm = ekf_tune_int("EKF_DOWNDATE_SLAB_BATCH", 0);
     const int slab = npairs > 1 ? slabm : slab1;
-    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith)
-                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith);
+    return storage == 0 ? launch_downdate_t<double>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith, aux)
+                        : launch_downdate_t<float>(st, dst, work, nwork, work_xcd, xcd_len, pstart, npairs, grid_cap, slab, s, kname, nx, extracted, arith, aux);
+}
+
+// Strip work list (flush32_pipe.h): column ranges of kSeg consecutive OWNED 128-column items; within a range the 128-row slabs from the
+// diagonal down, each a segment of up to kSeg items; the segments, in that order, cut into 8 equal contiguous runs (the CUs of an XCD then
+// work on the same column range -- the same G -- at the same time) and interleaved run by run; padded with empty segments to a multiple of 8.
+int64_t build_strip_segments(const TileMap &tm, int64_t nt, std::vector<int4> &out) {
+    constexpr int L = ekf_pipe32::kSeg;
+    std::vector<std::vector<int4>> segs;
+    const int64_t ncj = 2 * nt, step = (int64_t)L * tm.world;            // a row owns every world-th tile of a range: ~L owned items per range
+    for (int64_t c0 = 0; c0 < ncj; c0 += step)
+        for (int64_t rs = 0; rs < 2 * nt; ++rs) {
+            const int64_t I = rs >> 1, cmax = 2 * I + 1;
+            if (cmax < c0) continue;
+            std::vector<int4> sg;
+            for (int64_t cj = c0; cj < c0 + step && cj <= cmax; ++cj) {
+                if (!tm.mine(I, cj >> 1)) continue;
+                sg.push_back(ekf_pipe32::strip_entry(tm, (int)I, (int)(cj >> 1), (int)(rs & 1), (int)(cj & 1)));
+                if ((int)sg.size() == L) { segs.push_back(sg); sg.clear(); }
+            }
+            if (!sg.empty()) segs.push_back(sg);
+        }
+    const size_t ns = segs.size(), per = (ns + 7) / 8;
+    out.assign(per * 8 * L, make_int4(0, 0, -1, -1));
+    for (int x = 0; x < 8; ++x) {
+        const size_t lo = ns * x / 8, hi = ns * (x + 1) / 8;
+        for (size_t q = lo; q < hi; ++q) std::copy(segs[q].begin(), segs[q].end(), out.begin() + ((q - lo) * 8 + x) * L);
+    }
+    return (int64_t)(per * 8);
 }
 
 hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_cost, double *sig_cost,

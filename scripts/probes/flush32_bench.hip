@@ -1,0 +1,246 @@
+// Probe for the F32-arithmetic pass over float tiles at 57-64 pairs: k_flush_strip32 (flush32_pipe.h: row strips, -K resident in LDS, loader
+// wavefronts, persistent) against k_flush_mfma32 (flush32_mfma.h, one work item per workgroup) and against a scalar fmaf reference, in ONE
+// process on one device.
+//   build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I ekf_slam_amd/csrc scripts/probes/flush32_bench.hip -o scripts/probes/flush32_bench
+//   run:    flush32_bench <landmarks> <npairs> [rounds=5] [check=1] [pstart=0] [reverse=0] [grid=256]      (STAMP=2: where a stage's cycles go)
+// check: every output entry of every kernel bit-equal to  tile + fmaf-chain(from zero, ring order)  (out of place, all tiles).
+// timing: in place, interleaved rounds, HIP events, median / min per kernel; TFLOP/s = 2 m n(n+1) / t, TB/s = 4 n(n+1) / t.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "flush32_mfma.h"
+#include "flush32_pipe.h"
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+__device__ __forceinline__ uint32_t mix(uint64_t i, uint32_t seed) {
+    uint64_t z = i * 0x9E3779B97F4A7C15ull + seed;
+    z ^= z >> 31; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 29; z *= 0x94D049BB133111EBull; z ^= z >> 32;
+    return (uint32_t)z;
+}
+__global__ void k_fill(float *p, int64_t n, uint32_t seed, float scale) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = ((int32_t)mix((uint64_t)i, seed) * (1.0f / 2147483648.0f)) * scale;
+}
+// planar / negated copies from the interleaved pairs: Kil[s][e][xy] -> Kn[s][xy][e] = -K,  Gil -> Gpl
+__global__ void k_planar(const float *il, float *pl, int64_t ldm, int64_t pair_stride, int pcap, float sign) {
+    const int64_t n = (int64_t)pcap * ldm;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / ldm, e = i - s * ldm;
+        pl[s * pair_stride + e] = sign * il[s * pair_stride + 2 * e];
+        pl[s * pair_stride + ldm + e] = sign * il[s * pair_stride + 2 * e + 1];
+    }
+}
+// the reference: one thread per entry, fmaf chain from zero in ring order, tile added once
+__global__ void k_ref(const float *tiles, float *out, const int2 *work, int64_t nwork, const float *Kil, const float *Gil, int64_t pair_stride,
+                      int pstart, int pcap, int npairs, TileMap tm) {
+    constexpr int T = 256;
+    const int2 ij = work[blockIdx.x / (T * T / 256)];
+    const int sub = blockIdx.x % (T * T / 256);
+    const int r = sub, c = threadIdx.x;              // 256 threads = one tile row
+    const int64_t off = tm.tile_offset(ij.x, ij.y) + (int64_t)r * T + c;
+    float acc = 0.0f;
+    for (int p = 0; p < npairs; ++p) {
+        const int64_t so = (int64_t)ring_slot(pstart, p, pcap) * pair_stride;
+        const float kx = Kil[so + 2 * ((int64_t)ij.x * T + r)], ky = Kil[so + 2 * ((int64_t)ij.x * T + r) + 1];
+        const float gx = Gil[so + 2 * ((int64_t)ij.y * T + c)], gy = Gil[so + 2 * ((int64_t)ij.y * T + c) + 1];
+        acc = fmaf(-kx, gx, acc);
+        acc = fmaf(-ky, gy, acc);
+    }
+    out[off] = tiles[off] + acc;
+}
+__global__ void k_diff(const float *a, const float *b, int64_t n, unsigned long long *bad, unsigned long long *first) {
+    unsigned long long mine = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (__float_as_uint(a[i]) != __float_as_uint(b[i])) { ++mine; atomicMin(first, (unsigned long long)i); }
+    if (mine) atomicAdd(bad, mine);
+}
+
+int main(int argc, char **argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : 4000;
+    const int npairs = argc > 2 ? atoi(argv[2]) : 64;
+    const int rounds = argc > 3 ? atoi(argv[3]) : 5;
+    const int check = argc > 4 ? atoi(argv[4]) : 1;
+    const int pstart = argc > 5 ? atoi(argv[5]) : 0;
+    const int reverse = argc > 6 ? atoi(argv[6]) : 0;
+    const int grid = argc > 7 ? atoi(argv[7]) : 256;
+    constexpr int T = 256;
+    const int64_t n_mm = 2 * N, nt = (n_mm + T - 1) / T, ldm = nt * T;
+    const int pcap = std::max(64, npairs);
+    TileMap tm = ekf_make_tilemap(T, 1, 0);
+    tm.reverse = reverse;
+    // work list as abi.hip::refresh_work builds it: 8 x 8 super-tiles in row-major order, flattened, cut into 8 equal runs
+    std::vector<int2> flat;
+    const int SS = 8;
+    const int64_t ns = (nt + SS - 1) / SS;
+    for (int64_t si = 0; si < ns; ++si)
+        for (int64_t sj = 0; sj <= si; ++sj)
+            for (int64_t I = si * SS; I < nt && I < (si + 1) * SS; ++I)
+                for (int64_t J = sj * SS; J <= I && J < (sj + 1) * SS; ++J) flat.push_back(make_int2((int)I, (int)J));
+    const size_t tot = flat.size();
+    size_t len = 0;
+    std::vector<int2> st[8];
+    for (int x = 0; x < 8; ++x) { st[x].assign(flat.begin() + (tot * x) / 8, flat.begin() + (tot * (x + 1)) / 8); len = std::max(len, st[x].size()); }
+    std::vector<int2> wx(8 * len, make_int2(-1, -1));
+    for (int x = 0; x < 8; ++x) std::copy(st[x].begin(), st[x].end(), wx.begin() + x * len);
+    int2 *d_work = nullptr, *d_flat = nullptr;
+    CHK(hipMalloc(&d_work, wx.size() * sizeof(int2)));
+    CHK(hipMemcpy(d_work, wx.data(), wx.size() * sizeof(int2), hipMemcpyHostToDevice));
+    CHK(hipMalloc(&d_flat, flat.size() * sizeof(int2)));
+    CHK(hipMemcpy(d_flat, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice));
+
+    // strip segments (k_flush_strip32): column ranges of kSeg 128-column items, within a range the 128-row slabs from the diagonal down;
+    // flattened in that order, cut into 8 equal runs (one per XCD stream), interleaved segment by segment, padded to a multiple of 8
+    std::vector<int4> segflat;
+    int64_t nsegs = 0;
+    {
+        const int LS = ekf_pipe32::kSeg;
+        std::vector<std::vector<int4>> sl;
+        const int64_t ncj = 2 * nt;
+        for (int64_t c0 = 0; c0 < ncj; c0 += LS)
+            for (int64_t rs = 0; rs < 2 * nt; ++rs) {
+                const int64_t I = rs >> 1, cmax = 2 * I + 1;
+                if (cmax < c0) continue;
+                std::vector<int4> sgm;
+                for (int64_t cj = c0; cj < c0 + LS && cj <= cmax; ++cj) sgm.push_back(ekf_pipe32::strip_entry(tm, (int)(rs >> 1), (int)(cj >> 1), (int)(rs & 1), (int)(cj & 1)));
+                // ROT=1: each row slab starts its walk along the column range at a different item, so that the CUs of an XCD -- all on
+                // the same column range -- do not ask for the same G lines at the same moment (every one of them would wait out the miss)
+                if (getenv("ROT") && atoi(getenv("ROT")) && sgm.size() > 1) std::rotate(sgm.begin(), sgm.begin() + (rs * 5) % sgm.size(), sgm.end());
+                sl.push_back(sgm);
+            }
+        const size_t ns = sl.size(), per = (ns + 7) / 8;
+        nsegs = (int64_t)per * 8;
+        segflat.assign((size_t)nsegs * LS, make_int4(0, 0, -1, -1));
+        for (int x = 0; x < 8; ++x) {
+            const size_t lo = ns * x / 8, hi = ns * (x + 1) / 8;
+            for (size_t q = lo; q < hi; ++q) std::copy(sl[q].begin(), sl[q].end(), segflat.begin() + ((q - lo) * 8 + x) * LS);
+        }
+    }
+    int4 *d_segs = nullptr;
+    CHK(hipMalloc(&d_segs, segflat.size() * sizeof(int4)));
+    CHK(hipMemcpy(d_segs, segflat.data(), segflat.size() * sizeof(int4), hipMemcpyHostToDevice));
+    const int64_t telems = (int64_t)tot * T * T, pair_stride = 2 * ldm;
+    float *tiles, *out_a = nullptr, *out_b = nullptr, *Kil, *Gil, *Kn, *Gpl, *zeros;
+    CHK(hipMalloc(&tiles, telems * 4));
+    CHK(hipMalloc(&Kil, pair_stride * pcap * 4)); CHK(hipMalloc(&Gil, pair_stride * pcap * 4));
+    CHK(hipMalloc(&Kn, pair_stride * pcap * 4)); CHK(hipMalloc(&Gpl, pair_stride * pcap * 4));
+    CHK(hipMalloc(&zeros, ekf_pipe32::kZeroFloats * 4));
+    {
+        std::vector<float> z(ekf_pipe32::kZeroFloats, 0.0f);
+        for (int i = 0; i < 256; ++i) z[i] = -0.0f;
+        CHK(hipMemcpy(zeros, z.data(), z.size() * 4, hipMemcpyHostToDevice));
+    }
+    k_fill<<<2048, 256>>>(tiles, telems, 1u, 10.0f);
+    k_fill<<<1024, 256>>>(Kil, pair_stride * pcap, 2u, 0.05f);
+    k_fill<<<1024, 256>>>(Gil, pair_stride * pcap, 3u, 0.05f);
+    k_planar<<<1024, 256>>>(Kil, Kn, ldm, pair_stride, pcap, -1.0f);
+    k_planar<<<1024, 256>>>(Gil, Gpl, ldm, pair_stride, pcap, 1.0f);
+    CHK(hipDeviceSynchronize());
+
+    auto launch_old = [&](float *dstp) {
+        const int64_t g32 = 8 * (int64_t)len * (T / 128) * (T / 128);
+        hipLaunchKernelGGL((k_flush_mfma32<T, 4, 2, 3, true>), dim3((unsigned)g32), dim3(256), 0, 0, (const float *)tiles, dstp, d_work, (int64_t)len,
+                           (const float *)Kn, (const float *)Gpl, pair_stride, pstart, pcap, npairs, tm);
+    };
+    typedef void (*fns_t)(const float *, float *, const int4 *, int64_t, const float *, const float *, int64_t, int64_t, int, int, int, TileMap, const float *, float *, unsigned long long *);
+    float *dump;
+    CHK(hipMalloc(&dump, (size_t)grid * 128 * 256 * 4));
+    struct VarS { const char *name; fns_t fn; int lds, threads, D; };
+    const VarS vs[] = {
+        { "k_flush_strip32<2,8>", ekf_pipe32::k_flush_strip32<2, 8>, ekf_pipe32::lds_bytes_strip<2>(), 1024, 2 },
+        { "k_flush_strip32<2,2>", ekf_pipe32::k_flush_strip32<2, 2>, ekf_pipe32::lds_bytes_strip<2>(), 640, 2 },
+        { "k_flush_strip32<3,2>", ekf_pipe32::k_flush_strip32<3, 2>, ekf_pipe32::lds_bytes_strip<3>(), 640, 3 },
+        { "k_flush_strip32<2,4>", ekf_pipe32::k_flush_strip32<2, 4>, ekf_pipe32::lds_bytes_strip<2>(), 768, 2 },
+        { "k_flush_strip32<3,4>", ekf_pipe32::k_flush_strip32<3, 4>, ekf_pipe32::lds_bytes_strip<3>(), 768, 3 },
+    };
+    constexpr int nvs = sizeof(vs) / sizeof(vs[0]);
+    for (int v = 0; v < nvs; ++v) CHK(hipFuncSetAttribute((const void *)vs[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, vs[v].lds));
+    auto launch_strip = [&](float *dstp, int v) {
+        hipLaunchKernelGGL(vs[v].fn, dim3(grid), dim3(vs[v].threads), vs[v].lds, 0, (const float *)tiles, dstp, d_segs, nsegs, (const float *)Kn,
+                           (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, (const float *)zeros, dump, (unsigned long long *)nullptr);
+    };
+    auto strip_ok = [&](int v) { return (npairs + 7) / 8 == 8; };      // (instantiated for eight stages: 57-64 pairs)
+    if (getenv("STAMP") && atoi(getenv("STAMP")) == 2) {
+        constexpr int NLs = 4;
+        CHK(hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<2, NLs, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_strip<2>()));
+        unsigned long long *d_st;
+        CHK(hipMalloc(&d_st, (size_t)grid * (8 + NLs) * 64));
+        CHK(hipMemset(d_st, 0, (size_t)grid * (8 + NLs) * 64));
+        for (int rep = 0; rep < 2; ++rep)
+            hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<2, NLs, 8, true>), dim3(grid), dim3(512 + 64 * NLs), ekf_pipe32::lds_bytes_strip<2>(), 0, (const float *)tiles, tiles, d_segs, nsegs, (const float *)Kn,
+                               (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, (const float *)zeros, dump, d_st);
+        CHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs((size_t)grid * (8 + NLs) * 8);
+        CHK(hipMemcpy(hs.data(), d_st, hs.size() * 8, hipMemcpyDeviceToHost));
+        double cs[8] = { 0 }, ls[8] = { 0 };
+        for (int b = 0; b < grid; ++b)
+            for (int w = 0; w < 8 + NLs; ++w)
+                for (int q = 0; q < 8; ++q) (w >= 8 ? ls : cs)[q] += (double)hs[((size_t)b * (8 + NLs) + w) * 8 + q];
+        const double stages = (double)tot * 4 / grid * ((npairs + 7) / 8), items = (double)tot * 4 / grid;
+        printf("k_flush_strip32<2,stamp> landmarks %lld pairs %d: s_memtime ticks per stage (per item where said)\n", (long long)N, npairs);
+        printf("  consumer: k-steps 0-2 %.1f | lgkmcnt+barrier %.1f | read + last k-step %.1f | epilogue/item %.1f | item switch/item %.1f\n", cs[0] / (8.0 * grid) / stages,
+               cs[1] / (8.0 * grid) / stages, cs[2] / (8.0 * grid) / stages, cs[3] / (8.0 * grid) / items, cs[4] / (8.0 * grid) / items);
+        printf("  consumer: wait for the tile loads at the item's end %.1f per item\n", cs[5] / (8.0 * grid) / items);
+        printf("  loader (of %d): issue (G) %.1f | counted vmcnt wait %.1f | barrier %.1f\n", NLs, ls[5] / grid / NLs / stages, ls[6] / grid / NLs / stages, ls[7] / grid / NLs / stages);
+        return 0;
+    }
+    int rc = 0;
+    if (check) {
+        CHK(hipMalloc(&out_a, telems * 4)); CHK(hipMalloc(&out_b, telems * 4));
+        unsigned long long *d_bad;
+        CHK(hipMalloc(&d_bad, 16));
+        auto compare = [&](const char *name) {
+            unsigned long long init[2] = { 0, ~0ull }, res[2];
+            CHK(hipMemcpy(d_bad, init, 16, hipMemcpyHostToDevice));
+            k_diff<<<2048, 256>>>(out_a, out_b, telems, d_bad, d_bad + 1);
+            CHK(hipDeviceSynchronize());
+            CHK(hipMemcpy(res, d_bad, 16, hipMemcpyDeviceToHost));
+            printf("check %-28s: %llu of %lld entries differ from the fmaf reference%s\n", name, res[0], (long long)telems, res[0] ? "  <-- WRONG" : "");
+            if (res[0]) { printf("   first at element %llu (tile slot %llu, row %llu, col %llu)\n", res[1], res[1] / (T * T), (res[1] / T) % T, res[1] % T); rc = 1; }
+        };
+        CHK(hipMemset(out_a, 0xff, telems * 4));
+        k_ref<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, out_a, d_flat, (int64_t)tot, Kil, Gil, pair_stride, pstart, pcap, npairs, tm);
+        CHK(hipDeviceSynchronize());
+        CHK(hipMemset(out_b, 0xee, telems * 4)); launch_old(out_b); CHK(hipDeviceSynchronize()); compare("k_flush_mfma32<256,4,2,3,e>");
+        for (int v = 0; v < nvs; ++v)
+            if (strip_ok(v)) { CHK(hipMemset(out_b, 0xee, telems * 4)); launch_strip(out_b, v); CHK(hipDeviceSynchronize()); compare(vs[v].name); }
+        CHK(hipFree(out_a)); CHK(hipFree(out_b));
+    }
+    if (rounds > 0) {
+        hipEvent_t e0, e1;
+        CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+        std::vector<std::string> names = { "k_flush_mfma32<256,4,2,3,early>" };
+        for (int v = 0; v < nvs; ++v) names.push_back(vs[v].name);
+        const int nk = (int)names.size();
+        std::vector<std::vector<float>> ms(nk);
+        for (int r = 0; r < rounds + 1; ++r)
+            for (int k = 0; k < nk; ++k) {
+                if (k >= 1 && !strip_ok(k - 1)) continue;
+                CHK(hipEventRecord(e0, 0));
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (k == 0) launch_old(tiles); else launch_strip(tiles, k - 1);
+                    tm.reverse ^= (reverse == 2);
+                }
+                CHK(hipEventRecord(e1, 0));
+                CHK(hipEventSynchronize(e1));
+                float t; CHK(hipEventElapsedTime(&t, e0, e1));
+                if (r > 0) ms[k].push_back(t / 3);
+            }
+        const double n = 3.0 + (double)n_mm;
+        for (int k = 0; k < nk; ++k) {
+            if (ms[k].empty()) continue;
+            std::sort(ms[k].begin(), ms[k].end());
+            const double med = ms[k][ms[k].size() / 2], mn = ms[k][0];
+            printf("%-34s landmarks %lld pairs %d: median %.4f ms  min %.4f ms   %.1f TFLOP/s  %.2f TB/s (B_alg)\n", names[k].c_str(), (long long)N,
+                   npairs, med, mn, 2.0 * 2 * npairs * n * (n + 1) / 2 / (med * 1e-3) / 1e12, 4.0 * n * (n + 1) / (med * 1e-3) / 1e12);
+        }
+    }
+    return rc;
+}

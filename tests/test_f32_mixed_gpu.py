@@ -50,7 +50,12 @@ def _run(engines, ref, steps, seed, appends=()):
                 ref.append(u, R, pos, ref.N + 1)
 
 
-@pytest.mark.parametrize("batch", [1, 8, 13, 40])
+def _pass_kernel(pairs):
+    """which kernel a pass of `pairs` pending pairs over float tiles in F32 arithmetic runs (kernels.hip::launch_flush_mfma)"""
+    return "k_flush_strip32<" if pairs > 56 else "k_flush_mfma32<256," if pairs > 2 else "k_flush_mfma<float,256,"
+
+
+@pytest.mark.parametrize("batch", [1, 8, 13, 40, 57, 64])
 def test_f32_arithmetic_pass_against_f64_oracle(batch, oracle_lib):
     from ekf_slam_amd import Engine
     from oracle.ekf_structured import StructuredEKF
@@ -61,10 +66,13 @@ def test_f32_arithmetic_pass_against_f64_oracle(batch, oracle_lib):
     ref = StructuredEKF(N + 8, "known")
     for q in (e, plain, ref):
         q.set_state(x, P, s)
-    _run([e, plain], ref, 40, 14, appends=(11, 29))
+    steps = 40 if batch < 57 else 2 * batch + 5              # (the strip form needs a full batch of 57-64 pairs to run at all)
+    _run([e, plain], ref, steps, 14, appends=(11, 29))
+    if batch >= 57:
+        assert e.downdate_kernel_name() == ("k_flush_strip32<3,4,8>", batch), e.downdate_kernel_name()
     e.flush()
-    name, pairs = e.downdate_kernel_name()                   # the run's last pass: 40 % batch pairs (one or two pairs take the F64-arithmetic kernel)
-    assert name.startswith("k_flush_mfma32<256," if pairs > 2 else "k_flush_mfma<float,256,"), (name, pairs)
+    name, pairs = e.downdate_kernel_name()                   # the run's last pass: steps % batch pairs (one or two pairs take the F64-arithmetic kernel)
+    assert name.startswith(_pass_kernel(pairs)), (name, pairs)
     assert plain.downdate_kernel_name()[0].startswith("k_flush_mfma<float,256,")
     ex, eP = rel_err(e.get_x(), ref.x), rel_err(e.get_P(), ref.P)
     px, pP = rel_err(plain.get_x(), ref.x), rel_err(plain.get_P(), ref.P)
@@ -88,7 +96,7 @@ def test_f32_arithmetic_needs_float_tiles_of_edge_256():
         Engine(capacity=64, storage="f16")
 
 
-@pytest.mark.parametrize("world,batch", [(2, 1), (4, 8), (8, 20)])
+@pytest.mark.parametrize("world,batch", [(2, 1), (4, 8), (8, 20), (2, 64), (3, 60)])
 def test_f32_arithmetic_sharded_equals_the_plain_engine_bitwise(world, batch, oracle_lib):
     from ekf_slam_amd import Engine
     from ekf_slam_amd.sharding import ShardGroup
@@ -162,6 +170,6 @@ def test_a_reused_handle_leaves_no_stale_float_pairs_beyond_a_smaller_map(how, t
     _run([used, fresh], None, 3 * batch + 1, 21, appends=(1, 2, 3, 4, 5, 7, 8, 9))     # 388 landmarks = 776 rows > 768
     assert used.N == fresh.N == N0 + 8 and 2 * used.N > 768
     used.flush(); fresh.flush()
-    assert used.downdate_kernel_name()[0].startswith("k_flush_mfma")
+    assert used.downdate_kernel_name()[0].startswith("k_flush_")
     np.testing.assert_array_equal(used.get_x(), fresh.get_x())
     np.testing.assert_array_equal(used.get_P(), fresh.get_P())
