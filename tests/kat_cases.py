@@ -349,3 +349,62 @@ K15_Z, K15_R = np.array([2.5, 10.0]), np.diag([.1, .125])
 K15_X_OUT = np.array([0.0, 0, 90, -10, 2.4])
 K15_P_OUT = K15_P_A.copy()
 K15_P_OUT[3, 3], K15_P_OUT[4, 4] = .75, .18
+
+# KAT-16  correction body with a FULL phi (EKF_SLAM.m:124-145): the off-diagonals of phi_k^-1 in K = P H' phi^-1 (:141-143), and the
+#         pivoting branch of the 2 x 2 inverse (|phi(2,1)| > |phi(1,1)|).  In KAT-5..15 phi is diagonal every time.
+#     x = [0 0 0 | 2 0],  z = [2.5, .025],  R = diag(.025, .125)  (= z .* Rc, Rc = [.01 5]),  P symmetric positive definite with
+#     P(1,2) = P(1,3) = P(1,4) = .1 and P(3,4) = -.1:
+#         P = [.2 .1 .1 .1 0; .1 .2 0 0 0; .1 0 .3 -.1 0; .1 0 -.1 .2 0; 0 0 0 0 .1]
+#     :125-138  delta = (2, 0), q = 4, z_k = [2; 0],  H_s = [-1 0 0 1 0; 0 -.5 -1 0 .5]                 (as KAT-5)
+#     G = H P:  row 1 = -P(1,:) + P(4,:)              = [-.1  -.1  -.2  .1  0  ]
+#               row 2 = -.5 P(2,:) - P(3,:) + .5 P(5,:) = [-.15 -.1  -.3  .1  .05]
+#     :141      phi = G H' + R:  phi11 = .1 + .1 + .025 = .225 (9/40);  phi12 = phi21 = (-.1)(-.5) + (-.2)(-1) = .25;
+#               phi22 = (-.1)(-.5) + (-.3)(-1) + (.05)(.5) + .125 = .5        -- |phi21| = .25 > phi11 = .225: the inverse pivots
+#               det = 9/80 - 1/16 = 1/20,  phi^-1 = 20 [.5 -.25; -.25 .225] = [10 -5; -5 4.5]
+#     :143      K = P H' phi^-1 = G' phi^-1 (P symmetric), row i = [G1(i) G2(i)] [10 -5; -5 4.5]:
+#               K = [-.25 -.175; -.5 .05; -.5 -.35; .5 -.05; -.25 .225]
+#     :144      nu = [.5; .025],  x+ = x + K nu = [-.129375  -.24875  -.25875  2.24875  -.119375]
+#     :145      P+ = P - K G (every entry moves; exact values as 1/800ths below)
+K16_X = np.array([0.0, 0, 0, 2, 0])
+K16_P = np.array([
+    [.2, .1, .1, .1, 0],
+    [.1, .2, 0, 0, 0],
+    [.1, 0, .3, -.1, 0],
+    [.1, 0, -.1, .2, 0],
+    [0, 0, 0, 0, .1]])
+K16_Z, K16_R = np.array([2.5, .025]), np.diag([.025, .125])
+K16_PHI = np.array([[.225, .25], [.25, .5]])
+K16_K = np.array([[-.25, -.175], [-.5, .05], [-.5, -.35], [.5, -.05], [-.25, .225]])
+K16_X_OUT = np.array([-.129375, -.24875, -.25875, 2.24875, -.119375])
+K16_P_OUT = np.array([
+    [119, 46, -2, 114, 7],
+    [46, 124, -68, 36, -2],
+    [-2, -68, 76, -12, 14],
+    [114, 36, -12, 124, 2],
+    [7, -2, 14, 2, 71]]) / 800.0
+
+# KAT-17  association with robot-landmark cross-covariance (Correspondence.m:49-87): KAT-7's scene (x = [0 0 0 | 2 0 | 0 4], s = [5 5],
+#         R = diag(.025, 50)) with a non-zero strip P(1:3, 4:7), so that the cross terms of H_k P H_k' (:66) enter the position cost (:69)
+#         and FLIP the decision of the commented-out likelihood (:74, w_pos = 1, s_cost = 1) relative to KAT-7's diagonal P.
+#     z = [3, 45, 5]:  landmark 1 (2,0): nu = [3 - 2; 45 - 0] = [1; 45];  landmark 2 (0,4): z_k = [4; 90], nu = [-1; -45]
+#     KAT-7's P = diag(.1 .1 .1 .5 .5 .3 .3):  phi_1 = diag(.625, 50.25),  phi_2 = diag(.425, 50.125)
+#         pc = [1/.625 + 2025/50.25,  1/.425 + 2025/50.125] = [8/5 + 2700/67,  40/17 + 16200/401] = [41.8985..., 42.7519...]  -> landmark 1
+#     with the strip  P(1,4) = .2,  P(3,5) = .05,  P(2,7) = -.05  (and their mirrors; P stays positive definite):
+#         landmark 1, H_s = [-1 0 0 1 0; 0 -.5 -1 0 .5] on rows {1,2,3,4,5}:
+#             phi11 = P11 - 2 P14 + P44 + R11 = .1 - .4 + .5 + .025 = .225
+#             phi22 = .25 P22 + P33 + .25 P55 - 2 (.5) P35 + R22 = .025 + .1 + .125 - .05 + 50 = 50.2;   phi12 = 0
+#         landmark 2, H_s = [0 -1 0 0 1; .25 0 -1 -.25 0] on rows {1,2,3,6,7}:
+#             phi11 = P22 - 2 P27 + P77 + R11 = .1 + .1 + .3 + .025 = .525;   phi22 = .00625 + .1 + .01875 + 50 = 50.125;   phi12 = 0
+#         pc = [1/.225 + 2025/50.2,  1/.525 + 2025/50.125] = [40/9 + 10125/251,  40/21 + 16200/401] = [44.7830..., 42.3037...]  -> landmark 2
+#     live line :75 (w_pos = 0): signature costs 0, 0 -> first index either way
+K17_X = np.array([0.0, 0, 0, 2, 0, 0, 4])
+K17_S = [5.0, 5.0]
+K17_R = np.diag([.025, 50.0])
+K17_Z = [3.0, 45.0, 5.0]
+K17_P_DIAG = np.diag([.1, .1, .1, .5, .5, .3, .3])
+K17_P = K17_P_DIAG.copy()
+K17_P[0, 3] = K17_P[3, 0] = .2
+K17_P[2, 4] = K17_P[4, 2] = .05
+K17_P[1, 6] = K17_P[6, 1] = -.05
+K17_PC_DIAG = np.array([8 / 5 + 2700 / 67, 40 / 17 + 16200 / 401])
+K17_PC = np.array([40 / 9 + 10125 / 251, 40 / 21 + 16200 / 401])

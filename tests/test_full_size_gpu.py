@@ -353,3 +353,66 @@ def test_config5_shape_eight_shards_equal_the_single_gpu_engine_bitwise(storage,
             merged[hole] = blk[hole]
         np.testing.assert_array_equal(merged, a)
     g.close(); one.close()
+
+
+def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
+    """configs[4] at its own size against a restatement that is NOT the engine: oracle/ekf_factored.py keeps the landmark block of P implicit
+    (bulk-loaded diag(d) + U U', the appended panels, one rank-2 term per correction) and evaluates every read EKF_SLAM.m:40-51, :67-98,
+    :124-145 make of P from that form in F64 -- pinned to the literal-dense restatement at N <= 200 (tests/test_oracle_factored.py, 1e-11).
+    40 000 landmarks bulk-loaded, 224 steps of predict + append + correction (the appended landmarks are corrected too, every 7th step),
+    the F64-tile engine and the mixed-precision engine ("F32 mixed precision with F64 innovation solve": float tiles, the pass in F32
+    arithmetic at batch 64, i.e. the strip kernel) on the same inputs.  Compared: x, the robot rows P(1:3, :), the two rows of seven landmarks
+    (bulk-loaded and appended ones) over ALL columns, every landmark's own 2 x 2 block.  Tolerances: F64 tiles 1e-6 relative (BASELINE.json;
+    measured 1e-13), float tiles the bound DESIGN.md section 5 states for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x."""
+    import json, os
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.world import World
+    from oracle.ekf_factored import FactoredEKF
+    N0, steps = 40000, 224
+    cap = N0 + steps
+    w = World(cap, 20260101 + 5)
+    rng = np.random.default_rng(77)
+    n0 = 3 + 2 * N0
+    x = np.concatenate([[0.0, 0.0, 0.0], w.landmarks[:N0].reshape(-1)])
+    d = rng.uniform(0.01, 0.1, n0)
+    U = rng.normal(0.0, 0.01, (n0, 8))
+    s = np.arange(1, N0 + 1.0)
+    ref = FactoredEKF(cap, "known", max_terms=steps + 4, max_appends=steps + 4)
+    eng = {"f64": Engine(mode="known", capacity=cap, storage="f64", batch=16), "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64)}
+    for e in list(eng.values()) + [ref]:
+        e.load_lowrank_state(x, s, d, U)
+    Rc = [.01, 5.0]
+    for t in range(steps):
+        u = w.step()
+        k = (t * 37) % N0 if t % 7 else N0 + (t * 5) % (t + 1)           # every 7th step: a landmark appended on the way (incl. the newest)
+        (_, r, b), = w.observe([k])
+        R = np.diag([r * Rc[0], b * Rc[1]])
+        for e in eng.values():
+            e.predict(u); e.append(u, R, w.landmarks[N0 + t], N0 + t + 1); e.correct([r, b], R, k)
+        ref.predict(u); ref.append(u, R, w.landmarks[N0 + t], N0 + t + 1); ref.correct([r, b], R, k + 1)
+    assert ref.N == cap and all(e.N == cap for e in eng.values())
+    assert eng["f32_mixed"].downdate_kernel_name()[0].startswith("k_flush_strip32<")      # three full 64-pair passes ran
+    n = 3 + 2 * cap
+    rows = [0, 127, 20000, N0 - 1, N0, N0 + 100, cap - 1]                # landmarks whose two rows are compared over all columns
+    Dref = ref.diag_blocks()
+    rec = {"landmarks": [N0, cap], "update_steps": steps}
+    tol = {"f64": (1e-6, 1e-6), "f32_mixed": (1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps)}
+    for name, e in eng.items():
+        ex = rel_err(e.get_x(), ref.x)
+        er = rel_err(e.get_P_block(0, 0, 3, n), ref.P_rows(0, 3))
+        scale = max(float(np.abs(ref.P_rows(3 + 2 * k, 2)).max()) for k in rows)
+        el = max(float(np.abs(e.get_P_block(3 + 2 * k, 0, 2, n) - ref.P_rows(3 + 2 * k, 2)).max()) for k in rows) / scale
+        Dg = e.get_P_diag_blocks()[1:]                                   # [0] is P(1:2, 1:2)
+        edg = float(np.abs(Dg - Dref).max() / np.abs(Dref).max())
+        rec[name] = {"deferred_batch": int(e.cfg.batch), "rel_err_x": ex, "rel_err_robot_rows": er, "rel_err_landmark_rows": el, "rel_err_diagonal_blocks": edg,
+                     "tolerance_x": tol[name][0], "tolerance_P": tol[name][1]}
+    print("configs[4] at 40 000 landmarks against the factored oracle: %s" % json.dumps(rec))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_vs_factored_oracle.json"), "w") as fh:
+            json.dump(rec, fh)
+    for name in eng:
+        r, (tx, tP) = rec[name], tol[name]
+        assert r["rel_err_x"] <= tx and r["rel_err_robot_rows"] <= tP and r["rel_err_landmark_rows"] <= tP and r["rel_err_diagonal_blocks"] <= tP, rec
+    for e in eng.values():
+        e.close()

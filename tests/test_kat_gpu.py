@@ -228,3 +228,50 @@ def test_kat15_append_then_correct_the_appended_landmark_on_the_gpu(tile, batch)
         np.testing.assert_allclose(e.get_P(), K.K15_P_OUT, rtol=0, atol=2e-16)
         np.testing.assert_array_equal(e.get_s(), [5.0])
         e.close()
+
+
+@pytest.mark.parametrize("tile,batch", _SHAPES)
+def test_kat16_correction_with_a_full_phi_on_the_gpu(tile, batch):
+    """KAT-16 (tests/kat_cases.py): phi_k full, its inverse taken on the pivoting branch (|phi21| > |phi11|): k_gather's solve against the
+    paper values of K = P H' phi^-1, x+ and P+ (EKF_SLAM.m:141-145)."""
+    from ekf_slam_amd import Engine
+    e = Engine(capacity=4, tile=tile, batch=batch)
+    e.set_state(K.K16_X, K.K16_P, [1.0])
+    e.correct(K.K16_Z, K.K16_R, 0)
+    np.testing.assert_allclose(e.get_x(), K.K16_X_OUT, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(e.get_P(), K.K16_P_OUT, rtol=0, atol=2e-16)
+    e.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_kat17_association_with_cross_covariance_on_the_gpu(batch):
+    """KAT-17 (tests/kat_cases.py): the strip P(1:3, 4:7) enters k_associate's phi_k (Correspondence.m:66) and flips the w_pos = 1 decision
+    relative to the diagonal P of KAT-7; the live, signature-only likelihood (:75) is unmoved."""
+    from ekf_slam_amd import Engine
+    for P, pc, w_pos, want in ((K.K17_P_DIAG, K.K17_PC_DIAG, 1.0, (False, 1)), (K.K17_P, K.K17_PC, 1.0, (False, 2)), (K.K17_P, K.K17_PC, 0.0, (False, 1))):
+        e = Engine(mode="uc", capacity=4, tile=16, batch=batch, s_cost=1.0, s_thresh=1e9, w_pos=w_pos)
+        e.set_state(K.K17_X, P, K.K17_S)
+        new, idx0, pcs, sc = e.associate(K.K17_Z, K.K17_R, want_costs=True)
+        assert (new, idx0 + 1) == want, (w_pos, want)
+        np.testing.assert_allclose(pcs, pc, rtol=1e-14)
+        e.close()
+
+
+@pytest.mark.parametrize("device_assoc", [0, 1, 2, 3])
+def test_kat17_in_the_measure_loop_of_every_association_mode(device_assoc):
+    """the same scene through EKF_SLAM_UC.measure (EKF_SLAM_UC.m:107-151) in the four association modes: with the reference's live likelihood
+    the row corrects landmark 1 whatever the strip holds -- all modes leave the same bits"""
+    from ekf_slam_amd import Engine
+    ref = None
+    e = Engine(mode="uc", capacity=4, tile=16, batch=1, device_assoc=device_assoc)
+    e.set_state(K.K17_X, K.K17_P, K.K17_S)
+    e.measure([K.K17_Z], [0.0, 0.0], [1.0, 2.0, 3.0], [[2.0, 0.0], [0.0, 4.0], [9.0, 9.0]])
+    x, P = e.get_x(), e.get_P()
+    assert e.N == 2 and np.isfinite(x).all()
+    host = Engine(mode="uc", capacity=4, tile=16, batch=1, device_assoc=0)
+    host.set_state(K.K17_X, K.K17_P, K.K17_S)
+    R = np.diag([K.K17_Z[0] * .1, K.K17_Z[1] * 5.0])                   # EKF_SLAM_UC.m:110, Rc = [.1 5]
+    host.correct(K.K17_Z[:2], R, 0)
+    np.testing.assert_array_equal(x, host.get_x())
+    np.testing.assert_array_equal(P, host.get_P())
+    e.close(); host.close()

@@ -322,3 +322,43 @@ def test_kat15_append_then_correct_the_appended_landmark_by_hand(oracle_lib):
         np.testing.assert_allclose(e.x, K.K15_X_OUT, rtol=0, atol=2e-15, err_msg=name)
         np.testing.assert_allclose(e.P, K.K15_P_OUT, rtol=0, atol=2e-16, err_msg=name)
         np.testing.assert_array_equal(np.asarray(e.s, dtype=float), [5.0])
+
+
+def test_kat16_correction_with_a_full_phi_by_hand(oracle_lib):
+    """EKF_SLAM.m:124-145 (KAT-16): phi_k is a full 2 x 2 matrix (phi12 = .25), its inverse has off-diagonals [10 -5; -5 4.5] and is taken
+    on the pivoting branch (|phi21| > |phi11|); K, x+ and P+ worked out as exact rationals in tests/kat_cases.py -- all three restatements."""
+    from oracle.ekf_factored import FactoredEKF
+    from oracle.matlab_compat import inv2
+    assert abs(K.K16_PHI[1, 0]) > abs(K.K16_PHI[0, 0])
+    np.testing.assert_allclose(inv2(K.K16_PHI), [[10, -5], [-5, 4.5]], rtol=0, atol=2e-14)
+    fac = FactoredEKF(4, "known")
+    for name, e, correct in _both() + [("factored", fac, fac.correct)]:
+        if name == "factored":
+            e.set_state(K.K16_X, K.K16_P, [1.0])
+        else:
+            _load(e, K.K16_X, K.K16_P, [1.0])
+        correct(K.K16_Z, K.K16_R, 1)
+        np.testing.assert_allclose(e.x, K.K16_X_OUT, rtol=0, atol=1e-15, err_msg=name)
+        np.testing.assert_allclose(e.P, K.K16_P_OUT, rtol=0, atol=2e-16, err_msg=name)
+
+
+def test_kat17_association_sees_the_robot_landmark_cross_covariance_by_hand(oracle_lib):
+    """Correspondence.m:66-69 (KAT-17): with a non-zero strip P(1:3, 4:7) the cross terms of H_k P H_k' change the position costs and the
+    decision of the commented-out likelihood (:74, w_pos = 1) flips from landmark 1 (KAT-7's diagonal P) to landmark 2."""
+    from oracle.ekf_factored import FactoredEKF
+    c = D.Correspondence(1.0, 1e9, 'EKF_SLAM_UC')
+    for P, pc in ((K.K17_P_DIAG, K.K17_PC_DIAG), (K.K17_P, K.K17_PC)):
+        assert c.estimateCorrespondence(K.K17_Z, K.K17_R, K.K17_X, P, K.K17_S) == (False, 1)       # the live line :75: signature only
+        np.testing.assert_allclose(c.last_position_cost, pc, rtol=1e-14)
+    assert K.K17_PC_DIAG[0] < K.K17_PC_DIAG[1] and K.K17_PC[0] > K.K17_PC[1]
+    for P, pc, want in ((K.K17_P_DIAG, K.K17_PC_DIAG, (False, 1)), (K.K17_P, K.K17_PC, (False, 2))):
+        st = StructuredEKF(4, "uc", s_cost=1.0, s_thresh=1e9, w_pos=1.0)
+        st.set_state(K.K17_X, P, K.K17_S)
+        new, idx, pcs, sc = st.associate(K.K17_Z, K.K17_R, want_costs=True)
+        assert (new, idx) == want
+        np.testing.assert_allclose(pcs, pc, rtol=1e-14)
+        fac = FactoredEKF(4, "uc")
+        fac.set_state(K.K17_X, P, K.K17_S)
+        fac.s_cost, fac.w_pos = 1.0, 1.0
+        assert fac.estimateCorrespondence(K.K17_Z, K.K17_R) == want
+        np.testing.assert_allclose(fac.last_position_cost, pc, rtol=1e-14)
