@@ -111,8 +111,8 @@ struct ekf_handle {
     // inside its own 4 MiB L2); stream x is work_xcd[x * xcd_len .. ), padded with (-1,-1)
     int2 *d_work_xcd = nullptr;
     int64_t xcd_len = 0;
-    // cfg.pass_arith = EKF_ARITH_F32: the strip form of the pass (flush32_pipe.h) -- its work list, the page of zeros, the dump area
-    PassAux aux = { nullptr, 0, nullptr, nullptr, 0 };
+    // cfg.pass_arith = EKF_ARITH_F32: the strip form of the pass (flush32_pipe.h) -- its work list, the dump area
+    PassAux aux = { nullptr, 0, nullptr, 0 };
     int4 *d_segs = nullptr;
     int64_t segs_cap = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
@@ -1090,7 +1090,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->pass_arith == EKF_ARITH_F32) {
         HIPCHK(h, dalloc(h, &h->st.Gp32, (size_t)(2 * ldm) * h->st.pcap * 2));
         h->st.Kp32 = h->st.Gp32 + (size_t)(2 * ldm) * h->st.pcap;
-        // the strip form of the pass: work list (every item once + one padded segment per 128-row slab and column range at most), zeros, dump
+        // the strip form of the pass: work list (every item once + one padded segment per 128-row slab and column range at most), dump
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
         h->aux.grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -1099,15 +1099,8 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         const int64_t ranges = (2 * nt_cap + ekf_pipe32::kSeg * world - 1) / (ekf_pipe32::kSeg * world);
         h->segs_cap = 4 * slots + (2 * nt_cap * ranges + 8) * ekf_pipe32::kSeg;
         HIPCHK(h, dalloc(h, &h->d_segs, (size_t)h->segs_cap));
-        float *zeros = nullptr, *dump = nullptr;
-        HIPCHK(h, dalloc(h, &zeros, (size_t)ekf_pipe32::kZeroFloats));
-        {
-            float z[ekf_pipe32::kZeroFloats];
-            for (int i = 0; i < ekf_pipe32::kZeroFloats; ++i) z[i] = i < 256 ? -0.0f : 0.0f;
-            HIPCHK(h, hipMemcpy(zeros, z, sizeof z, hipMemcpyHostToDevice));
-        }
+        float *dump = nullptr;
         HIPCHK(h, dalloc(h, &dump, (size_t)h->aux.grid * ekf_pipe32::kDumpFloats));
-        h->aux.zeros = zeros;
         h->aux.dump = dump;
     }
     HIPCHK(h, dalloc(h, &h->st.small, 32));

@@ -10,8 +10,8 @@
 // Here one persistent workgroup per CU keeps the matrix pipe fed (k_flush_strip32 below; how it got there: profiles/round4_tuning.md).
 //
 // Operand layout (DevState::Kp32 / Gp32 as the gather writes them, "planar"): slot s, plane xy, element e at
-// [s * pair_stride + xy * ldm + e]; the K copies are stored NEGATED (-(float)K: exact), so the pieces are plain copies.  Pairs beyond
-// npairs in the last stage come from a page of zeros (-0.0f for -K, +0.0f for G: fmaf(-0, +0, acc) == acc for every acc).
+// [s * pair_stride + xy * ldm + e]; the K copies are stored NEGATED (-(float)K: exact).  Pairs beyond npairs in the last stage of eight
+// enter as -0.0f (-K) and +0.0f (G): fmaf(-0, +0, acc) == acc for every acc.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,32 +23,8 @@ namespace ekf_pipe32 {
 typedef float f4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kItem = 128;                          // a work item: 128 rows x 128 columns of a 256 x 256 float tile
-constexpr int kPiece = 1024;                        // one LDS-DMA wave instruction: 64 lanes x 16 bytes
-constexpr int kKBytes = 64 * kPiece;                // -K of one 128-row slab for 64 pairs: one piece per pair
-constexpr int kZeroFloats = 512;                    // the page of zeros: [0, 256) -0.0f, [256, 512) +0.0f
+constexpr int kPiece = 1024;                        // G of one pair for an item's 128 columns: 2 planes x 128 floats
 constexpr int kDumpFloats = kItem * 256;            // per workgroup: where its first item's meaningless first stores go
-
-// one 1 KiB piece: lane l's 16 bytes at base + voff -> LDS [lds_dst + 16 l]  (M0 is compiler-reserved: saved and restored)
-__device__ __forceinline__ void glds16(const void *base, uint32_t voff, uint32_t lds_dst) {
-    uint32_t keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate must be a literal)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-    switch (n) {
-#define EKF_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        EKF_VM(0) EKF_VM(1) EKF_VM(2) EKF_VM(3) EKF_VM(4) EKF_VM(5) EKF_VM(6) EKF_VM(7) EKF_VM(8) EKF_VM(9) EKF_VM(10) EKF_VM(11) EKF_VM(12) EKF_VM(13) EKF_VM(14) EKF_VM(15) EKF_VM(16) EKF_VM(17) EKF_VM(18) EKF_VM(19) EKF_VM(20) EKF_VM(21) EKF_VM(22) EKF_VM(23) EKF_VM(24) EKF_VM(25) EKF_VM(26) EKF_VM(27) EKF_VM(28) EKF_VM(29) EKF_VM(30) EKF_VM(31) EKF_VM(32) EKF_VM(33) EKF_VM(34) EKF_VM(35) EKF_VM(36) EKF_VM(37) EKF_VM(38) EKF_VM(39) EKF_VM(40) EKF_VM(41) EKF_VM(42) EKF_VM(43) EKF_VM(44) EKF_VM(45) EKF_VM(46) EKF_VM(47) EKF_VM(48)
-#undef EKF_VM
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-// every LDS read of this wavefront retired, then the workgroup's barrier (raw: __syncthreads() would drain the LDS-DMA queue)
-__device__ __forceinline__ void lds_done_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 // kStamp (diagnostic builds only, scripts/probes/flush32_bench.hip): s_memtime stamps around the segments of a stage, summed per
 // wavefront in scalar registers and written to `stamps` ([workgroup][wave][8] cycles) at the end; never the product kernel.
@@ -61,22 +37,28 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Row strips with -K RESIDENT in LDS, dedicated LOADER wavefronts, eight consumer wavefronts.
-// What its two predecessors taught (a 512-thread workgroup per CU with every wavefront issuing its own pieces; 256-thread workgroups,
-// two or three per CU; profiles/round4_tuning.md, scripts/probes/glds_issue_rate.hip, glds_coexec.hip):
-//   * an LDS-DMA instruction issued from inside an MFMA stream stalls its wavefront for hundreds of cycles, and both wavefronts of a SIMD
-//     do it at the same moment (lockstep behind the stage's barrier): no consumer may issue operand loads;
-//   * a CU keeps only ~24 LDS-DMA pieces in flight: at L2 latency that is 60-80 GB/s, at HBM latency under this kernel's load ~12 GB/s --
-//     so the TILE (half of all bytes, always an HBM miss) must not travel by LDS-DMA.  Each consumer loads the sixteen-byte pieces its own
-//     lanes will add and store straight into registers at the item's start (plain loads, eight per wavefront; their latency has the whole
-//     item's matrix work to hide behind), and LDS-DMA carries only the L2-resident operands;
-//   * operand bytes: a workgroup walks ALONG A ROW STRIP -- up to kSeg consecutive 128-column items of one 128-row slab -- and keeps that
-//     slab's -K for all pending pairs in LDS (64 KiB at 64 pairs), loaded once per strip segment: per item only G (64 KiB at 64 pairs).
-// LDS: -K 2 x 64 KiB (the strip segment in work, and the next one's, requested during this one's last item) | G ring (D + 1) x 8 KiB.
+// Row strips: eight wavefronts per CU, -K in their REGISTERS, G of a whole item double-buffered in LDS, ONE barrier per item.
+// How it got here (profiles/round4_tuning.md; scripts/probes/glds_issue_rate.hip, glds_coexec.hip, mfma_issue_rate.hip):
+//   * LDS-DMA is out: an LDS-DMA instruction issued from inside an MFMA stream stalls its wavefront for hundreds of cycles, and a CU keeps
+//     only ~8 of them in flight (60-78 GB/s at L2 latency, ~10 GB/s beyond it).  The TILE (half of all bytes, always an HBM miss) travels as
+//     plain loads into the registers of the wavefront that will add and store it, with half an item's matrix work to hide behind; G --
+//     asked for by every CU of an XCD at the same moment, so every request waits out the same miss -- as plain loads TWO ITEMS ahead;
+//   * a barrier per 8-pair stage (-K in LDS, a ring of G stages) left the matrix pipe idle for 590 of a stage's 2 670 cycles.  As the A
+//     operand of v_mfma_f32_16x16x4_f32, the -K of 32 rows for all 64 pairs is 64 registers, constant along a row strip: with -K out of LDS
+//     a whole item's G (64 KiB at 64 pairs) fits twice, and the wavefronts run an item's 256 MFMAs each with no synchronisation at all;
+//   * every LDS read costs its wavefront ~28 cycles of MFMA issue, prefetched or not (8 MFMAs + two 16-byte reads: 39 cycles per MFMA
+//     instead of 32), and the SIMD's arbiter serves the older of its two wavefronts first, strictly: the younger only fills gaps.  So a
+//     wavefront owns 32 rows x 64 columns -- ONE 16-byte read per eight MFMAs;
+//   * that shape needs ~175 registers, more than the 168 a third wavefront per SIMD would leave: there are no loader wavefronts.  Each
+//     wavefront carries an eighth of the NEXT-BUT-ONE item's G in registers (eight 16-byte pieces, loaded during this item, written to the
+//     free LDS buffer during the next one's first half): a whole item (~8 us) for the round trip;
+//   * operand bytes: a workgroup walks ALONG A ROW STRIP -- up to kSeg consecutive 128-column items of one 128-row slab; -K is fetched once
+//     per strip segment (64 dword loads per wavefront), per item only G.
+// LDS: G of the item in work | G of the next item (kS x 8 KiB each).
 constexpr int kSeg = 16;                            // items per strip segment (the work list is cut into segments of kSeg entries)
-template <int D> constexpr int lds_bytes_strip() { return 2 * kKBytes + (D + 1) * 8 * kPiece; }
+template <int kS> constexpr int lds_bytes_strip() { return 2 * kS * 8 * kPiece; }
 
-struct StripItem { int64_t toff, krow0, gcol0; bool ok; };
+struct StripItem { int64_t toff; int krow0, gcol0; };      // krow0 < 0: none  (no padding bytes: a padded struct is copied through scratch)
 
 // one work-list entry for the item (tile (I, J), row half `slab`, column half `cpart`); (0, 0, -1, -1) pads a short segment
 inline int4 strip_entry(const TileMap &tm, int I, int J, int slab, int cpart) {
@@ -84,30 +66,24 @@ inline int4 strip_entry(const TileMap &tm, int I, int J, int slab, int cpart) {
     return make_int4((int)(uint32_t)(toff & 0xffffffffll), (int)(uint32_t)((uint64_t)toff >> 32), I * 256 + slab * kItem, J * 256 + cpart * kItem);
 }
 
-// kS: stages per item = ceil(npairs / 8) (a template parameter: see the tile traffic below); NL loader wavefronts (1, 2, 4 or 8): piece x
-// of a stage / of -K is loader x % NL's
-template <int D, int NL = 2, int kS = 8, bool kStamp = false>
-__global__ __launch_bounds__(512 + 64 * NL)
+// kS: stages of eight pairs per item = ceil(npairs / 8) (a template parameter: the k-step loop is unrolled, see the tile traffic below)
+template <int kS = 8, bool kStamp = false>
+__global__ __launch_bounds__(512)
 void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                      const float *__restrict__ Kn, const float *__restrict__ G, int64_t pair_stride, int64_t ldm, int pstart, int pcap,
-                     int npairs, TileMap tm, const float *__restrict__ zeros, float *__restrict__ dump, unsigned long long *__restrict__ stamps = nullptr) {
-    constexpr int R = D + 1, T = 256, P = 8;      // a stage: eight pairs = four k-steps of v_mfma_f32_16x16x4_f32
-    constexpr uint32_t kKres = 0, kRing = 2 * kKBytes, kSlot = 8 * kPiece;
-    static_assert(NL == 1 || NL == 2 || NL == 4 || NL == 8, "loader wavefronts");
+                     int npairs, TileMap tm, float *__restrict__ dump, unsigned long long *__restrict__ stamps = nullptr) {
+    constexpr int T = 256, NP = 8 * kS, NK = 4 * kS;                       // pair pieces and k-steps (of v_mfma_f32_16x16x4_f32) per item
+    constexpr uint32_t kBuf = (uint32_t)NP * kPiece;                       // one item's G: pair piece p at p KiB, plane xy at + 512 xy
+    static_assert(kS >= 5 && kS <= 8, "stages per item (the G pieces and the tile pieces move in the first 16 k-steps)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 8;
-    const int lid = wave - 8;                                             // which loader
     const int lr = lane >> 4, lc = lane & 15;
-    constexpr int S = kS;                                                 // stages per item; the launcher guarantees kS == ceil(npairs / 8) > D
-    static_assert(kS > D + 1 && kS <= 8, "stages per item");
     unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;
     auto mark = [&](int which) { if constexpr (kStamp) { const unsigned long long t = stamp_now(); seg[which] += t - tprev; tprev = t; } };
 
     // ---- the work list: segment sg = blockIdx.x + k gridDim.x, entries segs[sg * kSeg ..), each (tile-store offset of the item's first
-    // entry: low, high word; first landmark-block row; first landmark-block column), precomputed by the host (strip_entry below): the index
+    // entry: low, high word; first landmark-block row; first landmark-block column), precomputed by the host (strip_entry above): the index
     // arithmetic from (I, J, sub-block) costs ~1 200 scalar cycles per item and wavefront, with the matrix pipe idle ----
     int nbase = 0;                                                        // this workgroup's entry numbers nbase .. nbase + 63 sit in `ent`
     int4 ent;
@@ -126,13 +102,12 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
     ent = load_entries(0);
     int nnext = 0;
     auto next_item = [&]() {
-        StripItem q; q.ok = false; q.toff = 0; q.krow0 = 0; q.gcol0 = 0;
+        StripItem q; q.toff = 0; q.krow0 = -1; q.gcol0 = 0;
         while (nnext < nent) {
             const int n = nnext++;
             if (n - nbase >= 64) { nbase = n; ent = load_entries(nbase); }
             const int kr = __builtin_amdgcn_readlane(ent.z, n - nbase);
             if (kr < 0) continue;                                          // padding of a short segment
-            q.ok = true;
             q.toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(ent.y, n - nbase) << 32) | (uint32_t)__builtin_amdgcn_readlane(ent.x, n - nbase));
             q.krow0 = kr;
             q.gcol0 = __builtin_amdgcn_readlane(ent.w, n - nbase);
@@ -141,171 +116,152 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
         return q;
     };
     StripItem cur = next_item();
-    if (!cur.ok) return;
-    StripItem nxt = next_item(), nn = nxt;                                 // nn: the item after next, looked up in the middle of each item
+    if (cur.krow0 < 0) return;
+    StripItem nxt = next_item(), nn = next_item();                         // the items after this one
+    auto slot_of = [&](int p) { int sl = pstart + p; if (sl >= pcap) sl -= pcap; return sl; };
 
-    if (loader) {
-        // =========================== the loader wavefronts ===========================
-#if !defined(EKF_LOADER_PRIO0)
-        __builtin_amdgcn_s_setprio(3);     // the youngest wavefront of its SIMD would lose every issue arbitration to the two MFMA streams beside it
-#endif
-        const uint32_t g_lane = ((uint32_t)(lane >> 5) * (uint32_t)ldm + 4u * (uint32_t)(lane & 31)) * 4u;
-        const uint32_t k_lane = ((uint32_t)(lane & 1) * (uint32_t)ldm + 4u * (uint32_t)(lane >> 1)) * 4u;
-        const uint32_t z_lane = (uint32_t)lane * 16;
-        auto slot_of = [&](int p) { int sl = pstart + p; if (sl >= pcap) sl -= pcap; return sl; };
-        auto issue_k = [&](const StripItem &q, int kb) {                   // all pairs' -K for q's row slab into buffer kb: one piece per pair
-            for (int p = lid; p < S * P; p += NL) {
-                const bool real = p < npairs;
-                glds16(real ? Kn + (int64_t)slot_of(real ? p : 0) * pair_stride + q.krow0 : zeros, real ? k_lane : z_lane,
-                       lds0 + kKres + (uint32_t)kb * kKBytes + (uint32_t)p * kPiece);
-            }
-        };
-        constexpr int kKPieces = (S * P + NL - 1) / NL;                    // (an upper bound on this loader's share; waits only get stricter)
-        auto issue_g = [&](const StripItem &q, int s, int slot) {          // this loader's share of the eight pairs of stage s
+    // wavefront w: rows 32 (w >> 1) .. + 31 of the item, columns 64 (w & 1) .. + 63: two row blocks x four column blocks of 16 x 16.  Lane
+    // (lr, lc) holds, of k-step g (k = 4 g + lr: pair 2 g + (lr >> 1), plane lr & 1): A = -K(row 32 wi + 16 rb + lc, k) in ka[rb][g];
+    // B = G(k, columns 64 wj + 4 lc + e) in fb[.][e] -- ONE 16-byte LDS read per k-step feeds eight MFMAs; accumulators acc[rb][e][i] = entry
+    // (row 32 wi + 16 rb + 4 lr + i, column 64 wj + 4 lc + e): the lane's tile piece p = 4 rb + i is sixteen consecutive bytes of that row.
+    const int wi = wave >> 1, wj = wave & 1;
+    const uint32_t b_off = (uint32_t)(lr >> 1) * kPiece + (uint32_t)(lr & 1) * 512 + (uint32_t)wj * 256 + (uint32_t)lc * 16;       // + buf kBuf + g 2 KiB
+    const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * T + 64 * wj + 4 * lc) * 4;
+    float ka[2][NK];
+    const uint32_t k_lane = (uint32_t)(lr & 1) * (uint32_t)ldm + (uint32_t)(32 * wi + lc);
+    auto load_k = [&](const StripItem &q) {
+        // (32-bit element offsets from a scalar base, recomputed here each time: hoisted out of the item loop, the addresses spill)
+        uint32_t kl = k_lane;
+        int ps = pstart, h = lr >> 1;
+        asm volatile("" : "+v"(kl), "+v"(h), "+s"(ps));
+        const float *kq = Kn + q.krow0;
 #pragma unroll
-            for (int ii = 0; ii < P / NL; ++ii) {
-                const int i = lid + NL * ii, p = P * s + i;
-                const bool real = q.ok && p < npairs;
-                glds16(real ? G + (int64_t)slot_of(real ? p : 0) * pair_stride + q.gcol0 : zeros + 256, real ? g_lane : z_lane,
-                       lds0 + kRing + (uint32_t)slot * kSlot + (uint32_t)i * kPiece);
-            }
-        };
-        int kb = 0;                                                        // -K buffer of the item in work
-        issue_k(cur, kb);
+        for (int g = 0; g < NK; ++g) {                                     // all 8 kS loads in flight at once (pairs beyond npairs: pair 0's, masked below)
+            const int p = 2 * g + h;
+            int sl = ps + (p < npairs ? p : 0);
+            sl -= sl >= pcap ? pcap : 0;
+            const uint32_t o = (uint32_t)sl * (uint32_t)pair_stride + kl;
+            ka[0][g] = kq[o];
+            ka[1][g] = kq[o + 16];
+        }
+    };
+    auto mask_k = [&]() {
 #pragma unroll
-        for (int s = 0; s <= D; ++s) issue_g(cur, s, s);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");                            // (P) the first item's -K and first stages are in LDS
-        int slot = 0;
-        if constexpr (kStamp) tprev = stamp_now();
-        for (;;) {
-            const bool newk = nxt.ok && nxt.krow0 != cur.krow0;
-            for (int s = 0; s < S; ++s) {
-                // stage s + 1 (of this item, or the next one's first) was requested D iterations ago, at the end of iteration s - D; younger
-                // than its pieces: the (D - 1) P / NL pieces of the iterations since, and -- in iterations 1 .. D of an item whose successor
-                // starts a new row slab -- this loader's share of that slab's -K, requested at the end of iteration 0.  (From iteration
-                // D + 1 on those pieces are OLDER than what is waited for: in-order return has them in LDS before barrier D + 1, seven
-                // stages before the first consumer reads them.)
-                mark(5);
-                wait_vmcnt((D - 1) * (P / NL) + ((newk && s >= 1 && s <= D) ? kKPieces : 0) > 48 ? 48 : (D - 1) * (P / NL) + ((newk && s >= 1 && s <= D) ? kKPieces : 0));
-                mark(6);
-                asm volatile("s_barrier" ::: "memory");                    // (S) publishes stage s + 1; every consumer has read stage s
-                mark(7);
-                {
-                    const int sn = s + 1 + D;
-                    if (sn < S) issue_g(cur, sn, slot); else issue_g(nxt, sn - S, slot);
-                }
-                if (newk && s == 0) issue_k(nxt, kb ^ 1);                  // the other buffer's last reader finished an item ago at least
-                if (s == 0) nn = next_item();
-                slot = slot + 1 == R ? 0 : slot + 1;
-            }
-            if (!nxt.ok) break;
-            if (newk) kb ^= 1;
-            cur = nxt;
-            nxt = nn;
+        for (int g = 0; g < NK; ++g) {
+            const bool in = 2 * g + (lr >> 1) < npairs;
+            ka[0][g] = in ? ka[0][g] : -0.0f;
+            ka[1][g] = in ? ka[1][g] : -0.0f;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (kStamp) {
-            if (lane == 0)
-                for (int q = 0; q < 8; ++q) stamps[((int64_t)blockIdx.x * (8 + NL) + wave) * 8 + q] = seg[q];
-        }
-        return;
-    }
-
-    // =========================== the eight consumer wavefronts ===========================
-    const uint32_t b_off = kRing + (uint32_t)(lr >> 1) * kPiece + (uint32_t)(lr & 1) * 512 + (uint32_t)lc * 16;       // + slot kSlot + ks 2 KiB + bp 256
-    const int arow = 16 * wave + lc;
-    const uint32_t a_off = kKres + (uint32_t)(lr >> 1) * kPiece + (uint32_t)(((arow >> 2) * 8) + (lr & 1) * 4 + (arow & 3)) * 4;   // + (8 s + 2 ks) KiB
-    const uint32_t t_lane = (uint32_t)((16 * wave + 4 * lr) * T + 4 * lc) * 4;
-    // Tile traffic, spread over the item instead of bursting at its ends (8 loads + 8 stores per wavefront, both wavefronts of a SIMD at
-    // once, cost 5 500 of an item's 27 000 cycles: STAMP=2).  ONE register buffer of eight 16-byte pieces carries two items at a time: in
-    // the item's first half each piece's register first gives up the PREVIOUS item's finished entries (a store), then takes the CURRENT
-    // item's tile value (a load, which has at least half an item to arrive); at the item's end the accumulators are added into it.
-    // For hipcc to get the waits right the STAGE LOOP IS UNROLLED (kS stages, a template parameter): with a run-time stage index it cannot
-    // tell which piece registers have a load pending and puts s_waitcnt vmcnt(0) in front of every store -- which then waits out the load
-    // issued two instructions earlier, a full HBM round trip per piece (450 cycles each, measured).  Unrolled, it sees that no store names
-    // a register with a pending load and the only wait is the one in front of the final adds.  (Loads hidden in asm are not an option: the
-    // register allocator moves the destination registers of asm outputs around before the data has landed.)
-    // (Moving the partner wavefronts' pieces to another k-step of the stage -- two positions in one instruction stream -- makes hipcc
-    // assume the first position's loads pending at the second and wait; two copies of the unrolled stage loop spill.  Not done.)
+    };
+    // G on its way: this wavefront's pair pieces w, w + 8, ... (lane l: plane l >> 5, columns 4 (l & 31) ..) of the item after next, in
+    // registers from one item's first half to the next one's, where they are written to the LDS buffer the barrier in between has freed
+    constexpr int GQ = NP / 8;
+    f4_t gq[GQ];
+    const uint32_t g_lane = ((uint32_t)(lane >> 5) * (uint32_t)ldm + 4u * (uint32_t)(lane & 31)) * 4u;
+    const f4_t gzero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    auto load_g = [&](const StripItem &q, int j) {
+        const int p = wave + 8 * j;
+        gq[j] = *reinterpret_cast<const f4_t *>(reinterpret_cast<const char *>(G + (int64_t)slot_of(p < npairs ? p : 0) * pair_stride + (q.krow0 >= 0 ? q.gcol0 : 0)) + g_lane);
+    };
+    auto write_g = [&](int buf, int j) {
+        const int p = wave + 8 * j;
+        // (p < NP = 8 GQ; only the last stage has pairs beyond npairs -- the launcher guarantees kS == ceil(npairs / 8))
+        *reinterpret_cast<f4_t *>(smem + (uint32_t)buf * kBuf + (uint32_t)p * kPiece + (uint32_t)lane * 16) = (j < GQ - 1 || p < npairs) ? gq[j] : gzero;
+    };
+    // Tile traffic, spread over the item instead of bursting at its ends.  ONE register buffer of eight 16-byte pieces carries two items at
+    // a time: in the item's first half each piece's register first gives up the PREVIOUS item's finished entries (a store), then takes the
+    // CURRENT item's tile value (a load, which has at least half an item to arrive); at the item's end the accumulators are added into it.
+    // For hipcc to get the waits right the K-STEP LOOP IS UNROLLED (kS a template parameter): with a run-time index it cannot tell which
+    // piece registers have a load pending and puts s_waitcnt vmcnt(0) in front of every store -- which then waits out the load issued two
+    // instructions earlier, a full HBM round trip per piece (450 cycles each, measured).  Unrolled, it sees that no store names a register
+    // with a pending load and the only wait is the one in front of the final adds.  (Loads hidden in asm are not an option: the register
+    // allocator moves the destination registers of asm outputs around before the data has landed.)  The G pieces move the same way.
     f4_t acc[2][4], tl[8];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bp][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int e = 0; e < 4; ++e) acc[rb][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
     };
-    auto piece_off = [&](int p) { return (size_t)((p & 3) * T + 64 * (p >> 2)) * 4 + t_lane; };
-    constexpr int half = kS / 2 > 0 ? kS / 2 : 1;
-    constexpr int pps = (8 + half - 1) / half;                             // pieces per stage: 2 at 57-64 pairs (stages 0-3 of 8)
+    auto piece_off = [&](int p) { return (size_t)(((p >> 2) * 16 + (p & 3)) * T) * 4 + t_lane; };
     const char *out_base = reinterpret_cast<const char *>(dump + (size_t)blockIdx.x * (kItem * T)), *in_base = nullptr;     // dump: 128 KiB per workgroup
 #pragma unroll
     for (int p = 0; p < 8; ++p) tl[p] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
-    auto move_pieces = [&](int s) {                      // (s is a compile-time constant after unrolling)
-#pragma unroll
-        for (int p = 0; p < 8; ++p)
-            if (p >= s * pps && p < (s + 1) * pps) {
-                // (unconditional on purpose -- the workgroup's FIRST item stores its still meaningless registers to a dump area: with a
-                // conditional store hipcc loads into a temporary, waits for it at once and copies)
-#if defined(EKF_TILE_PLAIN)
-                *reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)) = tl[p];
-                tl[p] = *reinterpret_cast<const f4_t *>(in_base + piece_off(p));
-#else
-                __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
-                tl[p] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(p)));
-#endif
-            }
+    // fragment sets: the LDS read of k-step g + 2 is issued in front of the eight MFMAs of k-step g; the sched_barriers keep hipcc from
+    // sinking the reads to their uses
+    f4_t fb[4];
+    auto read_frag = [&](int buf, int g, f4_t &b) {
+        b = *reinterpret_cast<const f4_t *>(smem + b_off + (uint32_t)buf * kBuf + (uint32_t)g * (2 * kPiece));
     };
-    // four fragment sets, one per k-step of a stage: every LDS read is issued two k-steps (sixteen MFMAs) ahead of its use, so that the
-    // lgkmcnt(0) in front of the stage's barrier finds its reads long retired (read one k-step ahead, the last read of a stage sat
-    // directly in front of the barrier and its latency was paid there by every wavefront, every stage)
-    float fa[4];
-    f4_t fb[4][2];
-    auto read_frag = [&](int slot, int kbuf, int s, int ks, float &a, f4_t (&b)[2]) {
-        a = *reinterpret_cast<const float *>(smem + a_off + (uint32_t)kbuf * kKBytes + (uint32_t)(P * s + 2 * ks) * kPiece);
-        const uint32_t so = (uint32_t)slot * kSlot + (uint32_t)ks * (2 * kPiece);
-        b[0] = *reinterpret_cast<const f4_t *>(smem + b_off + so);
-        b[1] = *reinterpret_cast<const f4_t *>(smem + b_off + so + 256);
-    };
-    auto mfma_step = [&](float a, const f4_t (&b)[2]) {
+    auto mfma_step = [&](int g, const f4_t &b) {
 #pragma unroll
-        for (int bp = 0; bp < 2; ++bp)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[bp][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[bp][e], acc[bp][e], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) acc[rb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[rb][g], b[e], acc[rb][e], 0, 0, 0);
     };
+    // where a wavefront ARRIVES at the item's barrier: behind the MFMAs of the last k-step but two (its last fragment read has been issued)
+    constexpr int kBar = NK - 3;
+    constexpr int kG0 = kBar - 2 * (GQ - 1);                                         // the G pieces move at k-steps kG0, kG0 + 2, ... <= kBar: the tile pieces own the first half
+    static_assert(kG0 >= 0 && kG0 + 2 * (GQ - 1) <= kBar, "the G pieces are in LDS before the item's barrier");
+    static_assert(NK % 4 == 0, "k-steps per item");
+
+    // prologue: the first item's G straight into buffer 0, the second's into the registers
+#pragma unroll
+    for (int j = 0; j < GQ; ++j) load_g(cur, j);
+    load_k(cur);
+#pragma unroll
+    for (int j = 0; j < GQ; ++j) { write_g(0, j); load_g(nxt, j); }
+    mask_k();
     zero_acc();
-    asm volatile("s_barrier" ::: "memory");                                // (P)
-    int slot = 0, kb = 0;                                                  // G ring slot, -K buffer of the item in work
-    read_frag(slot, kb, 0, 0, fa[0], fb[0]);
-    read_frag(slot, kb, 0, 1, fa[1], fb[1]);
+    // The item's barrier, in two halves.  ARRIVE (k-step kBar: this wavefront has read the last of this item's G and written its share of
+    // the next item's): one LDS add.  WAIT (after the item's epilogue, in front of the next item's first fragment read): spin until all
+    // eight have arrived.  Between the two a wavefront runs its last k-steps and its epilogue (wait for the tile, 32 adds) -- with one
+    // s_barrier in place of the pair all eight did that at the same moment, the matrix pipe idle for ~1 400 cycles per item (STAMP=2).
+    __shared__ int arrived;
+    if (tid == 0) __hip_atomic_store(&arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // (P)
+    int buf = 0, target = 0;                                               // G buffer of the item in work; arrivals that open the next one
+    read_frag(buf, 0, fb[0]);
+    read_frag(buf, 1, fb[1]);
     if constexpr (kStamp) tprev = stamp_now();
     for (;;) {
-        const bool newk = nxt.ok && nxt.krow0 != cur.krow0;
-        const int kbn = newk ? kb ^ 1 : kb;                                // the next item's (a new row slab's -K arrived during this item)
+        const bool newk = nxt.krow0 >= 0 && nxt.krow0 != cur.krow0;
         in_base = reinterpret_cast<const char *>(tiles + cur.toff);
+        StripItem n3 = nn;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            // on entry: fragments of k-steps 0 and 1 are in (or on their way to) sets 0 and 1
-            read_frag(slot, kb, s, 2, fa[2], fb[2]);
-            mfma_step(fa[0], fb[0]);                                       // k-step 0
-            move_pieces(s);
-            if (s == S / 2) nn = next_item();                              // (scalar work, between the MFMAs)
-            read_frag(slot, kb, s, 3, fa[3], fb[3]);                       // the stage's last LDS read: after the barrier its slot is refilled
-            mfma_step(fa[1], fb[1]);                                       // k-step 1
-            mark(0);
-            lds_done_barrier();                                            // (S) stage s + 1 is visible
-            mark(1);
-            const int nslot = slot + 1 == R ? 0 : slot + 1;
-            read_frag(nslot, s + 1 < S ? kb : kbn, s + 1 < S ? s + 1 : 0, 0, fa[0], fb[0]);
-            mfma_step(fa[2], fb[2]);                                       // k-step 2
-            read_frag(nslot, s + 1 < S ? kb : kbn, s + 1 < S ? s + 1 : 0, 1, fa[1], fb[1]);
-            mfma_step(fa[3], fb[3]);                                       // k-step 3
-            slot = nslot;
-            mark(2);
+        for (int g = 0; g < NK; ++g) {
+            // on entry: the fragments of k-steps g and g + 1 are in (or on their way to) sets g & 3 and (g + 1) & 3
+            if (g + 2 < NK) read_frag(buf, g + 2, fb[(g + 2) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(g, fb[g & 3]);
+            if (g < 16 && g % 2 == 0) {
+                // (unconditional on purpose -- the workgroup's FIRST item stores its still meaningless registers to a dump area: with a
+                // conditional store hipcc loads into a temporary, waits for it at once and copies)
+                const int p = g / 2;
+                __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
+                tl[p] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(p)));
+            }
+            if (g >= kG0 && (g - kG0) % 2 == 0 && (g - kG0) / 2 < GQ) {     // the next item's G into the buffer the last barrier freed; the one after it on its way
+                write_g(buf ^ 1, (g - kG0) / 2);
+                load_g(nn, (g - kG0) / 2);
+            }
+            if (g == 7) mark(6);
+            if (g == 15) mark(7);
+            if (g == kBar) mark(0);
+            if (g == 17) n3 = next_item();                                 // (scalar work, between the MFMAs)
+            if (g == kBar) {                                               // ARRIVE: this item's last read (k-step NK - 1) has retired, the next item's G pieces are written
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // the item's result takes its tile's place in the registers; it leaves during the next item's first stages
+        mark(2);
+        // a new row slab: its -K replaces this one's as soon as the last MFMA has been issued
+        if (newk) load_k(nxt);
+        // the item's result takes its tile's place in the registers; it leaves during the next item's first half
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         mark(5);
+        if (newk) mask_k();
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
@@ -313,18 +269,24 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
         zero_acc();
         out_base = reinterpret_cast<const char *>(dst + cur.toff);
         mark(3);
-        if (!nxt.ok) break;
-        kb = kbn;
+        if (nxt.krow0 < 0) break;
+        buf ^= 1;
         cur = nxt;
         nxt = nn;
+        nn = n3;
         mark(4);
+        target += 8;                                                       // WAIT
+        while (__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        mark(1);
+        read_frag(buf, 0, fb[0]);
+        read_frag(buf, 1, fb[1]);
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p)                                            // the last item's result
         __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
     if constexpr (kStamp) {
         if (lane == 0)
-            for (int q = 0; q < 8; ++q) stamps[((int64_t)blockIdx.x * (8 + NL) + wave) * 8 + q] = seg[q];
+            for (int q = 0; q < 8; ++q) stamps[((int64_t)blockIdx.x * 8 + wave) * 8 + q] = seg[q];
     }
 }
 

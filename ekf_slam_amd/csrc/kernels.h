@@ -179,7 +179,6 @@ struct NextRow { int64_t j; double *send; };
 struct PassAux {
     const int4 *segs;      // strip work list: nsegs segments of ekf_pipe32::kSeg entries (strip_entry), 8 interleaved per-XCD streams
     int64_t nsegs;         // a multiple of 8
-    const float *zeros;    // kZeroFloats floats: [0, 256) -0.0f, [256, 512) +0.0f
     float *dump;           // kDumpFloats floats per workgroup of the pass's grid
     int grid;              // workgroups the dump area was sized for (one per CU)
 };

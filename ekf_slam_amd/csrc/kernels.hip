@@ -2046,17 +2046,18 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         int64_t grid = 8 * xcd_len * kSubs;
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if constexpr (sizeof(TS) == 4) {
-            if (arith == 1 && npairs > 56 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0 && st.tm.world >= 1) {
-                // 57-64 pairs (eight stages of eight): the strip form -- -K resident in LDS along a row strip, loader wavefronts, one persistent
-                // workgroup per CU (flush32_pipe.h): 7.6-7.8 ms against 8.1-8.5 at 40 000 landmarks and 64 pairs, same bits
-                constexpr int kD = 3, kNL = 4;
-                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<kD, kNL, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                   ekf_pipe32::lds_bytes_strip<kD>());
+            static const bool use_strip = ekf_tune_int("EKF_PASS_STRIP", 1) != 0;
+            if (use_strip && arith == 1 && npairs > 56 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0) {
+                // 57-64 pairs (eight stages of eight): the strip form -- one persistent workgroup per CU walks row strips with -K in its
+                // wavefronts' registers and a whole item's G double-buffered in LDS (flush32_pipe.h): 7.3 ms against 8.1-8.3 at 40 000
+                // landmarks and 64 pairs, same bits
+                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   ekf_pipe32::lds_bytes_strip<8>());
                 if (attr == hipSuccess) {
-                    hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<kD, kNL, 8>), dim3((unsigned)aux->grid), dim3(512 + 64 * kNL), ekf_pipe32::lds_bytes_strip<kD>(), s,
+                    hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<8>), dim3((unsigned)aux->grid), dim3(512), ekf_pipe32::lds_bytes_strip<8>(), s,
                                        (const float *)st.tiles, (float *)dstv, aux->segs, aux->nsegs, (const float *)st.Kp32, (const float *)st.Gp32, st.pair_stride,
-                                       st.ldm, pstart, st.pcap, npairs, st.tm, aux->zeros, aux->dump, (unsigned long long *)nullptr);
-                    if (kname) snprintf(kname, 64, "k_flush_strip32<%d,%d,8>", kD, kNL);
+                                       st.ldm, pstart, st.pcap, npairs, st.tm, aux->dump, (unsigned long long *)nullptr);
+                    if (kname) snprintf(kname, 64, "k_flush_strip32<8>");
                     return true;
                 }
             }

@@ -6,6 +6,7 @@
 // check: every output entry of every kernel bit-equal to  tile + fmaf-chain(from zero, ring order)  (out of place, all tiles).
 // timing: in place, interleaved rounds, HIP events, median / min per kernel; TFLOP/s = 2 m n(n+1) / t, TB/s = 4 n(n+1) / t.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -61,6 +62,27 @@ __global__ void k_diff(const float *a, const float *b, int64_t n, unsigned long 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (__float_as_uint(a[i]) != __float_as_uint(b[i])) { ++mine; atomicMin(first, (unsigned long long)i); }
     if (mine) atomicAdd(bad, mine);
+}
+
+// PREWARM_US: a register-only MFMA loop on every CU for about that long, launched right in front of each timed launch after the idle gap
+__global__ void k_prewarm(float *out, long long cycles) {
+    typedef float f4w __attribute__((ext_vector_type(4)));
+    f4w acc[4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+    const float a = threadIdx.x * 1e-3f, b = 1.0f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < (1 << 20); ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        if ((it & 63) == 63 && (long long)__builtin_readcyclecounter() - t0 > cycles) break;
+    }
+    if (acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0] == 12345.0f) out[threadIdx.x] = acc[0][1];
+}
+
+// PREWARM_MB: stream that many megabytes of the tile store through every CU right in front of each timed launch
+__global__ void k_prewarm_mem(const float4 *src, long long n, float *out) {
+    float4 a = { 0, 0, 0, 0 };
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) { const float4 v = src[i]; a.x += v.x; a.y += v.w; }
+    if (a.x + a.y == 12345.678f) out[threadIdx.x] = a.x;
 }
 
 int main(int argc, char **argv) {
@@ -127,16 +149,10 @@ int main(int argc, char **argv) {
     CHK(hipMalloc(&d_segs, segflat.size() * sizeof(int4)));
     CHK(hipMemcpy(d_segs, segflat.data(), segflat.size() * sizeof(int4), hipMemcpyHostToDevice));
     const int64_t telems = (int64_t)tot * T * T, pair_stride = 2 * ldm;
-    float *tiles, *out_a = nullptr, *out_b = nullptr, *Kil, *Gil, *Kn, *Gpl, *zeros;
+    float *tiles, *out_a = nullptr, *out_b = nullptr, *Kil, *Gil, *Kn, *Gpl;
     CHK(hipMalloc(&tiles, telems * 4));
     CHK(hipMalloc(&Kil, pair_stride * pcap * 4)); CHK(hipMalloc(&Gil, pair_stride * pcap * 4));
     CHK(hipMalloc(&Kn, pair_stride * pcap * 4)); CHK(hipMalloc(&Gpl, pair_stride * pcap * 4));
-    CHK(hipMalloc(&zeros, ekf_pipe32::kZeroFloats * 4));
-    {
-        std::vector<float> z(ekf_pipe32::kZeroFloats, 0.0f);
-        for (int i = 0; i < 256; ++i) z[i] = -0.0f;
-        CHK(hipMemcpy(zeros, z.data(), z.size() * 4, hipMemcpyHostToDevice));
-    }
     k_fill<<<2048, 256>>>(tiles, telems, 1u, 10.0f);
     k_fill<<<1024, 256>>>(Kil, pair_stride * pcap, 2u, 0.05f);
     k_fill<<<1024, 256>>>(Gil, pair_stride * pcap, 3u, 0.05f);
@@ -149,33 +165,29 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL((k_flush_mfma32<T, 4, 2, 3, true>), dim3((unsigned)g32), dim3(256), 0, 0, (const float *)tiles, dstp, d_work, (int64_t)len,
                            (const float *)Kn, (const float *)Gpl, pair_stride, pstart, pcap, npairs, tm);
     };
-    typedef void (*fns_t)(const float *, float *, const int4 *, int64_t, const float *, const float *, int64_t, int64_t, int, int, int, TileMap, const float *, float *, unsigned long long *);
+    typedef void (*fns_t)(const float *, float *, const int4 *, int64_t, const float *, const float *, int64_t, int64_t, int, int, int, TileMap, float *, unsigned long long *);
     float *dump;
     CHK(hipMalloc(&dump, (size_t)grid * 128 * 256 * 4));
     struct VarS { const char *name; fns_t fn; int lds, threads, D; };
     const VarS vs[] = {
-        { "k_flush_strip32<2,8>", ekf_pipe32::k_flush_strip32<2, 8>, ekf_pipe32::lds_bytes_strip<2>(), 1024, 2 },
-        { "k_flush_strip32<2,2>", ekf_pipe32::k_flush_strip32<2, 2>, ekf_pipe32::lds_bytes_strip<2>(), 640, 2 },
-        { "k_flush_strip32<3,2>", ekf_pipe32::k_flush_strip32<3, 2>, ekf_pipe32::lds_bytes_strip<3>(), 640, 3 },
-        { "k_flush_strip32<2,4>", ekf_pipe32::k_flush_strip32<2, 4>, ekf_pipe32::lds_bytes_strip<2>(), 768, 2 },
-        { "k_flush_strip32<3,4>", ekf_pipe32::k_flush_strip32<3, 4>, ekf_pipe32::lds_bytes_strip<3>(), 768, 3 },
+        { "k_flush_strip32<8>", ekf_pipe32::k_flush_strip32<8>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
     };
     constexpr int nvs = sizeof(vs) / sizeof(vs[0]);
     for (int v = 0; v < nvs; ++v) CHK(hipFuncSetAttribute((const void *)vs[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, vs[v].lds));
     auto launch_strip = [&](float *dstp, int v) {
         hipLaunchKernelGGL(vs[v].fn, dim3(grid), dim3(vs[v].threads), vs[v].lds, 0, (const float *)tiles, dstp, d_segs, nsegs, (const float *)Kn,
-                           (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, (const float *)zeros, dump, (unsigned long long *)nullptr);
+                           (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, dump, (unsigned long long *)nullptr);
     };
     auto strip_ok = [&](int v) { return (npairs + 7) / 8 == 8; };      // (instantiated for eight stages: 57-64 pairs)
     if (getenv("STAMP") && atoi(getenv("STAMP")) == 2) {
-        constexpr int NLs = 4;
-        CHK(hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<2, NLs, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_strip<2>()));
+        constexpr int NLs = 0;
+        CHK(hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_strip<8>()));
         unsigned long long *d_st;
         CHK(hipMalloc(&d_st, (size_t)grid * (8 + NLs) * 64));
         CHK(hipMemset(d_st, 0, (size_t)grid * (8 + NLs) * 64));
         for (int rep = 0; rep < 2; ++rep)
-            hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<2, NLs, 8, true>), dim3(grid), dim3(512 + 64 * NLs), ekf_pipe32::lds_bytes_strip<2>(), 0, (const float *)tiles, tiles, d_segs, nsegs, (const float *)Kn,
-                               (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, (const float *)zeros, dump, d_st);
+            hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<8, true>), dim3(grid), dim3(512 + 64 * NLs), ekf_pipe32::lds_bytes_strip<8>(), 0, (const float *)tiles, tiles, d_segs, nsegs, (const float *)Kn,
+                               (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, dump, d_st);
         CHK(hipDeviceSynchronize());
         std::vector<unsigned long long> hs((size_t)grid * (8 + NLs) * 8);
         CHK(hipMemcpy(hs.data(), d_st, hs.size() * 8, hipMemcpyDeviceToHost));
@@ -183,12 +195,18 @@ int main(int argc, char **argv) {
         for (int b = 0; b < grid; ++b)
             for (int w = 0; w < 8 + NLs; ++w)
                 for (int q = 0; q < 8; ++q) (w >= 8 ? ls : cs)[q] += (double)hs[((size_t)b * (8 + NLs) + w) * 8 + q];
-        const double stages = (double)tot * 4 / grid * ((npairs + 7) / 8), items = (double)tot * 4 / grid;
-        printf("k_flush_strip32<2,stamp> landmarks %lld pairs %d: s_memtime ticks per stage (per item where said)\n", (long long)N, npairs);
-        printf("  consumer: k-steps 0-2 %.1f | lgkmcnt+barrier %.1f | read + last k-step %.1f | epilogue/item %.1f | item switch/item %.1f\n", cs[0] / (8.0 * grid) / stages,
-               cs[1] / (8.0 * grid) / stages, cs[2] / (8.0 * grid) / stages, cs[3] / (8.0 * grid) / items, cs[4] / (8.0 * grid) / items);
-        printf("  consumer: wait for the tile loads at the item's end %.1f per item\n", cs[5] / (8.0 * grid) / items);
-        printf("  loader (of %d): issue (G) %.1f | counted vmcnt wait %.1f | barrier %.1f\n", NLs, ls[5] / grid / NLs / stages, ls[6] / grid / NLs / stages, ls[7] / grid / NLs / stages);
+        const double items = (double)tot * 4 / grid * 2;                // (two launches)
+        printf("k_flush_strip32<8,stamp> landmarks %lld pairs %d: s_memtime ticks per item and wavefront (ideal: 16384 for the two MFMA streams of a SIMD)\n", (long long)N, npairs);
+        printf("  consumer: k-steps up to the barrier %.1f | lgkmcnt+barrier %.1f | last two k-steps %.1f | -K + wait for the tile loads %.1f | adds %.1f | item switch %.1f\n", cs[0] / (8.0 * grid) / items,
+               cs[1] / (8.0 * grid) / items, cs[2] / (8.0 * grid) / items, cs[5] / (8.0 * grid) / items, cs[3] / (8.0 * grid) / items, cs[4] / (8.0 * grid) / items);
+        for (int w = 0; w < 8 + NLs; ++w) {
+            double a[8] = { 0 };
+            for (int b = 0; b < grid; ++b)
+                for (int q = 0; q < 8; ++q) a[q] += (double)hs[((size_t)b * (8 + NLs) + w) * 8 + q] / grid / (items / 2);
+            printf("  wave %2d:", w);
+            for (int q = 0; q < 8; ++q) printf(" %8.1f", a[q]);
+            printf("\n");
+        }
         return 0;
     }
     int rc = 0;
@@ -223,6 +241,22 @@ int main(int argc, char **argv) {
         for (int r = 0; r < rounds + 1; ++r)
             for (int k = 0; k < nk; ++k) {
                 if (k >= 1 && !strip_ok(k - 1)) continue;
+                const int gap_ms = getenv("GAP_MS") ? atoi(getenv("GAP_MS")) : 0;      // GAP_MS: an idle device between single timed launches (the engine's duty cycle)
+                if (gap_ms > 0) {
+                    for (int rep = 0; rep < 3; ++rep) {
+                        usleep(1000 * gap_ms);
+                        if (getenv("PREWARM_US")) hipLaunchKernelGGL(k_prewarm, dim3(grid * 2), dim3(256), 0, 0, dump, (long long)atoi(getenv("PREWARM_US")) * 2100);      // (readcyclecounter: shader cycles, ~2.1 GHz)
+                        if (getenv("PREWARM_MB")) hipLaunchKernelGGL(k_prewarm_mem, dim3(2048), dim3(256), 0, 0, (const float4 *)tiles, (long long)atoi(getenv("PREWARM_MB")) * 65536ll, dump);
+                        CHK(hipEventRecord(e0, 0));
+                        if (k == 0) launch_old(tiles); else launch_strip(tiles, k - 1);
+                        tm.reverse ^= (reverse == 2);
+                        CHK(hipEventRecord(e1, 0));
+                        CHK(hipEventSynchronize(e1));
+                        float t; CHK(hipEventElapsedTime(&t, e0, e1));
+                        if (r > 0) ms[k].push_back(t);
+                    }
+                    continue;
+                }
                 CHK(hipEventRecord(e0, 0));
                 for (int rep = 0; rep < 3; ++rep) {
                     if (k == 0) launch_old(tiles); else launch_strip(tiles, k - 1);

@@ -1,5 +1,5 @@
 #!/bin/bash
 set -o pipefail
-O=gpurun_out/flush32_ab.log
+O=gpurun_out/flush32_gap.log
 : > $O
-for r in 1 2; do for b in flush32_bench flush32_benchdekf_tile_plain flush32_benchdekf_loader_prio0; do echo "== $b" | tee -a $O; timeout -k 10 200 ./scripts/probes/$b 40000 64 3 0 | grep -E "strip|mfma32|WRONG" | tee -a $O; done; done
+(echo "== back to back"; timeout -k 10 200 ./scripts/probes/flush32_bench 40576 64 3 0 | grep -E "strip"; for w in 0 500 2000 6000; do echo "== 8 ms idle, MFMA prewarm $w us"; PREWARM_US=$w GAP_MS=8 timeout -k 10 200 ./scripts/probes/flush32_bench 40576 64 3 0 | grep -E "strip"; done; for w in 1024 8192; do echo "== 8 ms idle, stream $w MB first"; PREWARM_MB=$w GAP_MS=8 timeout -k 10 200 ./scripts/probes/flush32_bench 40576 64 3 0 | grep -E "strip"; done ) 2>&1 | tee -a $O

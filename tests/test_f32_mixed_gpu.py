@@ -69,7 +69,7 @@ def test_f32_arithmetic_pass_against_f64_oracle(batch, oracle_lib):
     steps = 40 if batch < 57 else 2 * batch + 5              # (the strip form needs a full batch of 57-64 pairs to run at all)
     _run([e, plain], ref, steps, 14, appends=(11, 29))
     if batch >= 57:
-        assert e.downdate_kernel_name() == ("k_flush_strip32<3,4,8>", batch), e.downdate_kernel_name()
+        assert e.downdate_kernel_name() == ("k_flush_strip32<8>", batch), e.downdate_kernel_name()
     e.flush()
     name, pairs = e.downdate_kernel_name()                   # the run's last pass: steps % batch pairs (one or two pairs take the F64-arithmetic kernel)
     assert name.startswith(_pass_kernel(pairs)), (name, pairs)

@@ -363,7 +363,10 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
     the F64-tile engine and the mixed-precision engine ("F32 mixed precision with F64 innovation solve": float tiles, the pass in F32
     arithmetic at batch 64, i.e. the strip kernel) on the same inputs.  Compared: x, the robot rows P(1:3, :), the two rows of seven landmarks
     (bulk-loaded and appended ones) over ALL columns, every landmark's own 2 x 2 block.  Tolerances: F64 tiles 1e-6 relative (BASELINE.json;
-    measured 1e-13), float tiles the bound DESIGN.md section 5 states for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x."""
+    measured 3e-16 .. 2e-15), float tiles: what is kept in F64 (x, the robot rows, the diagonal blocks) the bound DESIGN.md section 5 states
+    for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x; the landmark rows, whose off-diagonal entries ARE floats, 2e-7 of the
+    largest entry: an entry carries the float rounding of its own magnitude (6e-8 relative), and the cross-covariances between appended
+    landmarks (~10 beside diagonal blocks of ~17) make that 4e-8 of the max-norm -- measured 4.0e-8, the first pass's rounding, no drift."""
     import json, os
     from ekf_slam_amd import Engine
     from ekf_slam_amd.world import World
@@ -396,7 +399,7 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
     rows = [0, 127, 20000, N0 - 1, N0, N0 + 100, cap - 1]                # landmarks whose two rows are compared over all columns
     Dref = ref.diag_blocks()
     rec = {"landmarks": [N0, cap], "update_steps": steps}
-    tol = {"f64": (1e-6, 1e-6), "f32_mixed": (1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps)}
+    tol = {"f64": (1e-6, 1e-6, 1e-6), "f32_mixed": (1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps, 2e-7)}      # x, F64-kept parts of P, float-stored rows
     for name, e in eng.items():
         ex = rel_err(e.get_x(), ref.x)
         er = rel_err(e.get_P_block(0, 0, 3, n), ref.P_rows(0, 3))
@@ -405,14 +408,14 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
         Dg = e.get_P_diag_blocks()[1:]                                   # [0] is P(1:2, 1:2)
         edg = float(np.abs(Dg - Dref).max() / np.abs(Dref).max())
         rec[name] = {"deferred_batch": int(e.cfg.batch), "rel_err_x": ex, "rel_err_robot_rows": er, "rel_err_landmark_rows": el, "rel_err_diagonal_blocks": edg,
-                     "tolerance_x": tol[name][0], "tolerance_P": tol[name][1]}
+                     "tolerance_x": tol[name][0], "tolerance_P": tol[name][1], "tolerance_landmark_rows": tol[name][2]}
     print("configs[4] at 40 000 landmarks against the factored oracle: %s" % json.dumps(rec))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "config5_vs_factored_oracle.json"), "w") as fh:
             json.dump(rec, fh)
     for name in eng:
-        r, (tx, tP) = rec[name], tol[name]
-        assert r["rel_err_x"] <= tx and r["rel_err_robot_rows"] <= tP and r["rel_err_landmark_rows"] <= tP and r["rel_err_diagonal_blocks"] <= tP, rec
+        r, (tx, tP, tL) = rec[name], tol[name]
+        assert r["rel_err_x"] <= tx and r["rel_err_robot_rows"] <= tP and r["rel_err_landmark_rows"] <= tL and r["rel_err_diagonal_blocks"] <= tP, rec
     for e in eng.values():
         e.close()
