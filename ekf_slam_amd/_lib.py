@@ -18,7 +18,7 @@ EKF_COMM_ID_BYTES = 128
 EKF_STORE_F64, EKF_STORE_F32 = 0, 1
 EKF_ARITH_F64, EKF_ARITH_F32 = 0, 1
 (EKF_KERNEL_DOWNDATE, EKF_KERNEL_GATHER, EKF_KERNEL_PREDICT, EKF_KERNEL_ASSOCIATE, EKF_KERNEL_APPEND,
- EKF_KERNEL_COUNT) = range(6)
+ EKF_KERNEL_ROWPANEL, EKF_KERNEL_EXCHANGE, EKF_KERNEL_COUNT) = range(8)
 
 _d = ctypes.c_double
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -600,6 +600,7 @@ int32_t correct_begin(ekf_handle *h, const double z[2], const double R[4], int64
     if (h->nx_valid && h->nx_idx == idx && h->nx_N == h->N && h->npend == 0) {
         // the last pass over P left this row-panel in the send area (ekf_hint_next): nothing to extract
     } else {
+        TimedLaunch tl(h, EKF_KERNEL_ROWPANEL);
         HIPCHK(h, launch_rowpanel(h->st, h->pending_args.j, h->pending_args.n_mm, h->pstart, h->npend, corr_send(h, h->slab), h->storage,
                                   h->stream));
     }
@@ -629,7 +630,10 @@ int32_t prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m) {
     for (int32_t q = 0; q < m; ++q)
         REQUIRE(h, idx[q] >= 0 && idx[q] < h->N, EKF_ERR_INDEX, "prefetch: landmark index outside the state");
     const int64_t slab = slab_for(h, n_mm(h));
-    HIPCHK(h, launch_rowpanel_base(h->st, idx, m, n_mm(h), h->send, slab, h->storage, h->stream));
+    {
+        TimedLaunch tl(h, EKF_KERNEL_ROWPANEL);
+        HIPCHK(h, launch_rowpanel_base(h->st, idx, m, n_mm(h), h->send, slab, h->storage, h->stream));
+    }
     h->pf_valid = false;
     h->nx_valid = false;
     h->nx_valid = false;       // (a prefetch's all-gather overwrites the receive area the extracted panel sits in)
@@ -653,6 +657,7 @@ int32_t exchange_rccl(ekf_handle *h) {
             "sharded handle without a communicator: call ekf_comm_init, or drive the begin / your own all-gather / "
             "finish calls");
     const double *src = pending_send(h);
+    TimedLaunch tl(h, EKF_KERNEL_EXCHANGE);
     const int r = g_rccl.AllGather(src, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
     if (r != 0) { h->pending = false; return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r)); }
     return EKF_OK;

@@ -266,7 +266,10 @@ int32_t ekf_checkpoint_load(ekf_handle *h, const char *path);
 
 /* ---- measurement hooks ---- */
 enum { EKF_KERNEL_DOWNDATE = 0, EKF_KERNEL_GATHER = 1, EKF_KERNEL_PREDICT = 2, EKF_KERNEL_ASSOCIATE = 3,
-       EKF_KERNEL_APPEND = 4, EKF_KERNEL_COUNT = 5 };
+       EKF_KERNEL_APPEND = 4,
+       EKF_KERNEL_ROWPANEL = 5,   /* sharded handles: the extraction of a correction's (or a prefetch's) row-panels into the send area */
+       EKF_KERNEL_EXCHANGE = 6,   /* sharded handles with ekf_comm_init: the all-gather on the library's communicator */
+       EKF_KERNEL_COUNT = 7 };
 /* Bracket every launch of kernel `which` with HIP events on the handle's stream (on != 0; on > 512 also reserves
  * event pairs for that many launches between two reads, so that none is created inside a timed region) and read the
  * accumulated launch count and device time; reading synchronises the stream and resets the counters. */

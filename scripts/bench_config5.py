@@ -19,6 +19,28 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def load_pmc(N0, batch, storage):
+    """HBM bytes per full-batch launch of the pass from the newest committed PMC summary of this workload
+    (profiles/round*_config5_pmc.json: separate rocprofv3 --pmc passes of this command, profiles/README.md), else None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_config5_pmc.json")),
+                   key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
+    for path in reversed(files):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        for leg in rec.get("legs", []):
+            if leg.get("landmarks") == N0 and leg.get("batch") == batch and leg.get("storage") == storage:
+                return {"file": os.path.relpath(path, ROOT), "git_blob": bench.git_blob_hash(path), "kernel": leg.get("kernel"),
+                        "pairs_per_launch": leg.get("pairs_per_launch"), "landmarks_at_launch": leg.get("landmarks_at_launch"),
+                        "hbm_bytes_per_launch": leg.get("hbm_bytes_per_launch"), "matrix_pipe_busy": leg.get("matrix_pipe_busy"),
+                        "l2_hit_rate": leg.get("l2_hit_rate")}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--landmarks", type=int, default=40000)
@@ -71,6 +93,7 @@ def main():
     e_N = [N0]
     run(0, args.warmup)
     e.sync()
+    kernel_full, kpairs_full = e.downdate_kernel_name()       # the warm-up ended with a pass: a FULL batch when warmup % batch == 0
     e.timing_enable(L.EKF_KERNEL_DOWNDATE, True, launches=args.steps + 8)
     n_start = 3 + 2 * e_N[0]
     t0 = time.perf_counter()
@@ -85,17 +108,42 @@ def main():
     b_alg = w_bytes * n_mid * (n_mid + 1)
     avg_ms = ms / max(launches, 1)
     finite = bool(np.isfinite(e.get_x()).all())
-    out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I−KH)P vs roofline",
+    # Which roof binds the pass?  HBM: every unique entry of P read and written once (b_alg).  Matrix pipe: one launch applies
+    # `pairs` rank-2 terms to every stored entry -- 2 x 2 pairs FLOPs per entry of the lower triangle, n (n + 1) / 2 entries (the
+    # kernels compute whole diagonal tiles: counted as the triangle, the algorithmic figure).  `bound` is the roof with the larger
+    # achieved / peak: the one this launch shape sits closer to.
+    pairs_avg = args.steps / max(launches, 1)
+    flops = 4.0 * pairs_avg * n_mid * (n_mid + 1) / 2
+    f32_pass = args.storage == "f32_mixed"
+    pipe_peak = bench.F32_MATRIX_PEAK if f32_pass else bench.F64_MATRIX_PEAK
+    hbm_frac = b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK
+    pipe_frac = flops / (avg_ms * 1e-3) / pipe_peak
+    bound = "mfma" if pipe_frac > hbm_frac else "hbm"
+    pmc = load_pmc(N0, args.batch, args.storage)
+    if pmc is not None and pmc.get("kernel") and pmc["kernel"] not in kernel_full:
+        pmc = None                                            # measured on another kernel: does not describe these launches
+    roof = {"bound": bound,
+            "achieved": flops / (avg_ms * 1e-3) / 1e12 if bound == "mfma" else b_alg / (avg_ms * 1e-3) / 1e9,
+            "peak": pipe_peak / 1e12 if bound == "mfma" else bench.HBM_PEAK / 1e9,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": pipe_frac if bound == "mfma" else hbm_frac,
+            "roofs": {"hbm": {"achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac},
+                      "mfma": {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak / 1e12, "unit": "TFLOP/s", "frac": pipe_frac,
+                               "pipe": "v_mfma_f32_16x16x4_f32" if f32_pass else "v_mfma_f64_16x16x4_f64"}},
+            # HBM bytes per FULL-batch launch from PMC counters (their own rocprofv3 passes): from the committed summary of this
+            # launch shape, null when none matches
+            "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "from_committed_profile": pmc,
+            "kernel": kernel_full, "pairs_per_launch": kpairs_full, "last_launch": {"kernel": kernel, "pairs": kpairs},
+            "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
+            "algorithmic_flops_per_launch": flops, "update_steps_per_launch": pairs_avg}
+    out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I\u2212KH)P vs roofline",
            "value": args.steps / dt, "unit": "update-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s" % {"f32": "f32 tiles, f64 pass arithmetic", "f32_mixed": "f32 tiles, f32 pass arithmetic (matrix pipe)", "f64": "f64 tiles"}[args.storage], "data": "synthetic",
            "config": {"workload": "configs[4] shape on 1 GPU: %d -> %d landmarks, %s tile storage, F64 solve, step = predict + "
                                   "append + 1 correction (streaming landmark append)" % (N0 + args.warmup, e_N[0], args.storage),
                       "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
                       "bulk_load_s": t_load, "state_finite": finite},
-           "roofline": {"bound": "hbm", "achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK, "traffic": None, "kernel": kernel, "pairs_per_launch": kpairs,
-                        "launches": launches, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": b_alg,
-                        "update_steps_per_launch": args.steps / max(launches, 1)}}
+           "roofline": roof}
     print(json.dumps(out), flush=True)
 
 

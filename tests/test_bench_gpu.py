@@ -22,10 +22,16 @@ def test_default_bench_line_carries_the_other_single_gpu_configurations():
     b = json.loads(lines[0])
     assert b["n_gpus"] == 1 and b["unit"] == "update-steps/s" and b["value"] > 0 and b["config"]["state_finite"]
     assert b["roofline"]["bound"] == "hbm" and 0.5 < b["roofline"]["frac"] < 1.0 and "k_downdate_w" in b["roofline"]["kernel"]
-    assert "note" in b["config"]                                            # --steps < 256: the line says that its timed region is short
+    # a timed region under 0.2 s: the block is repeated, the median quoted, and the line says so
+    assert "note" in b["config"] and b["repeats"] >= 3 and b["repeats"] % 2 == 1
+    assert b["ms_per_step_min"] <= b["ms_per_step"] <= b["ms_per_step_max"]
+    assert b["deferred"]["deferred_batch"] == 20 and b["deferred_b32"]["deferred_batch"] == 32
     oc = b["other_configs"]
     c1, c4 = oc["configs[1]"], oc["configs[4] on one GPU"]
     assert "error" not in c1 and "error" not in c4, oc
     assert c1["value"] > 5e4 and c1["config"]["state_finite"] and "device-resident loop" in c1["config"]["device_association"]
-    assert c4["value"] > 1e3 and c4["config"]["state_finite"] and c4["roofline"]["kernel"].startswith(("k_flush_strip32<", "k_flush_mfma32<256,"))
+    assert c4["value"] > 1e3 and c4["config"]["state_finite"] and c4["roofline"]["kernel"].startswith("k_flush_strip32<")
+    r4 = c4["roofline"]
+    assert r4["bound"] in ("hbm", "mfma") and r4["frac"] == max(r4["roofs"]["hbm"]["frac"], r4["roofs"]["mfma"]["frac"])
+    assert r4["pairs_per_launch"] == 64 and 0.3 < r4["roofs"]["hbm"]["frac"] < 1.0 and 0.4 < r4["roofs"]["mfma"]["frac"] < 1.0
     assert c4["steps"] == 9936 and "50000 landmarks" in c4["config"]["workload"]
