@@ -68,6 +68,7 @@ SIGNATURES = {
                                  ctypes.POINTER(_i64)]),
     "ekf_exchange_set_buffers": (_i32, [_vp, _vp, _vp]),
     "ekf_exchange_local": (_i32, [ctypes.POINTER(_vp), _i32]),
+    "ekf_exchange_set_hook": (_i32, [_vp, _vp, _vp]),
     "ekf_shard_owner": (_i32, [_i32, _i64, _i64]),
     "ekf_shard_slot": (_i64, [_i32, _i64, _i64]),
     "ekf_shard_panel_source": (_i32, [_i32, _i64, _i64, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
@@ -129,3 +130,5 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+EXCHANGE_HOOK = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p)      # int32_t (*)(void *ctx): ekf_exchange_set_hook

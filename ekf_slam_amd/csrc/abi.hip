@@ -167,6 +167,8 @@ struct ekf_handle {
     bool nx_valid = false;
     int64_t nx_idx = -1, nx_N = 0;
     void *comm = nullptr;          // ncclComm_t
+    int32_t (*xhook)(void *) = nullptr;   // ekf_exchange_set_hook: the caller's all-gather, called where the library-owned one would run
+    void *xhook_ctx = nullptr;
     KernelTimer timers[EKF_KERNEL_COUNT];
     std::vector<void *> allocs;
     int64_t bytes = 0;
@@ -653,6 +655,11 @@ int32_t prefetch_finish(ekf_handle *h) {
 }
 
 int32_t exchange_rccl(ekf_handle *h) {
+    if (h->comm == nullptr && h->xhook != nullptr) {
+        // transport (d): the caller moves the pending contribution (ekf_exchange_info), between begin and finish as for (b) / (c)
+        const int32_t rc = h->xhook(h->xhook_ctx);
+        return rc == EKF_OK ? EKF_OK : fail(h, EKF_ERR_COMM, "the exchange hook reported a failure");
+    }
     REQUIRE(h, h->comm != nullptr, EKF_ERR_STATE,
             "sharded handle without a communicator: call ekf_comm_init, or drive the begin / your own all-gather / "
             "finish calls");
@@ -721,6 +728,28 @@ int32_t do_correct_dev(ekf_handle *h, const double z[2], const double R[4], int6
     if (rc) return rc;
     CorrectArgs a;
     fill_correct_args(h, a, z, R, idx);
+    if (h->sharded) {
+        // a shard: extraction of the row-panel of the landmark the DEVICE names (every shard holds the same winners: the association
+        // runs on replicated data -- x, s, the strip, the live diagonal blocks), the all-gather, the gather on the exchanged panel
+        REQUIRE(h, !h->pending, EKF_ERR_STATE, "correct: an exchange is pending");
+        h->slab = slab_for(h, a.n_mm);
+        {
+            TimedLaunch tl(h, EKF_KERNEL_ROWPANEL);
+            HIPCHK(h, launch_rowpanel_dev(h->st, a.j, a.n_mm, h->pstart, h->npend, corr_send(h, h->slab), h->storage, h->stream, dl));
+        }
+        h->nx_valid = false;
+        h->pending = true; h->pending_kind = 1; h->x_count = h->slab;
+        rc = exchange_rccl(h);
+        h->pending = false; h->pending_kind = 0;
+        if (rc) return rc;
+        {
+            TimedLaunch tl(h, EKF_KERNEL_GATHER);
+            const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
+            HIPCHK(h, launch_gather_sharded(h->st, a, fuse, h->recv, h->slab, 0, /*patched*/ true, h->storage, h->stream, &dl));
+            h->have_pp = false;
+        }
+        return finish_step(h);
+    }
     {
         TimedLaunch tl(h, EKF_KERNEL_GATHER);
         const PredictArgs *fuse = h->have_pp ? &h->pp : nullptr;
@@ -1290,10 +1319,11 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
     // middle of it: only the library-owned communicator can run that.  A host that runs the all-gather itself (transport (b)
     // / (c) of ekfslam.h) drives append / correct_begin / its exchange / correct_finish per row -- refused here, up front,
     // before any row has changed the state.
-    REQUIRE(h, !(h->sharded && h->comm == nullptr && m > 0), EKF_ERR_STATE,
-            "measure: a sharded handle needs the library-owned communicator (ekf_comm_init); with a host-run exchange call "
-            "ekf_append / ekf_correct_begin / ekf_correct_finish per observation");
-    if (h->sharded && h->comm && h->batch > 1 && m > 1 && h->N > 0) {
+    REQUIRE(h, !(h->sharded && h->comm == nullptr && h->xhook == nullptr && m > 0), EKF_ERR_STATE,
+            "measure: a sharded handle needs the library-owned communicator (ekf_comm_init) or an exchange hook "
+            "(ekf_exchange_set_hook); with a host-run exchange call ekf_append / ekf_correct_begin / ekf_correct_finish per observation");
+    const bool dev_loop = h->cfg.mode == EKF_MODE_UC && h->cfg.device_assoc == 3 && h->cfg.w_pos == 0.0;
+    if (h->sharded && (h->comm || h->xhook) && h->batch > 1 && m > 1 && h->N > 0 && !dev_loop) {      // (the device loop names its landmarks on the device)
         // the scan's corrections are known before the loop runs: fetch their base row-panels in ONE exchange
         // (rows that turn out to append drop the prefetch again; the per-row exchange then takes over)
         std::vector<int64_t> want;
@@ -1319,7 +1349,8 @@ int32_t ekf_measure(ekf_handle *h, const double *obs, int64_t m, const double u[
     // with no wait anywhere: which of the two it queues is the host mirror's prediction (exact when w_pos == 0: the reference's
     // live likelihood is a function of z(3) and s alone, Correspondence.m:71,75), what the device decided comes back in records
     // that are checked later (verify_loop).  With w_pos != 0 the host cannot predict the branch: the waited path below.
-    const bool dev_loop = h->cfg.mode == EKF_MODE_UC && h->cfg.device_assoc == 3 && h->cfg.w_pos == 0.0 && !h->sharded;
+    // On a shard the same loop runs on every rank (the association reads replicated data only, so every rank's device names the same
+    // landmark); a correction is k_rowpanel<kDev> (the panel of the landmark the device names) -> all-gather -> k_gather<sharded, kDev>.
     struct { bool have; int set; int32_t seq, nblk; } nxt = { false, 0, 0, 0 };     // winners of row ii's association already on the device
     if (dev_loop) {
         rc = verify_loop(h, /*block*/ false);                              // what earlier scans' launches have reported by now
@@ -1490,6 +1521,16 @@ int32_t ekf_exchange_set_buffers(ekf_handle *h, void *send, void *recv) {
     h->send = send ? (double *)send : h->own_send;
     h->recv = recv ? (double *)recv : h->own_recv;
     h->nx_valid = false;       // corr_send() may point elsewhere now: a hinted extraction sits in the old area
+    return EKF_OK;
+}
+
+int32_t ekf_exchange_set_hook(ekf_handle *h, int32_t (*hook)(void *), void *ctx) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    REQUIRE(h, h->sharded && !h->pending, EKF_ERR_STATE, "exchange_set_hook: not sharded, or an exchange is pending");
+    REQUIRE(h, h->comm == nullptr || hook == nullptr, EKF_ERR_STATE, "exchange_set_hook: the handle has a communicator of its own");
+    h->xhook = hook;
+    h->xhook_ctx = ctx;
+    h->nx_valid = false;
     return EKF_OK;
 }
 

@@ -154,16 +154,21 @@ int64_t gather_workgroups(const DevState &st, int64_t n_mm);
 // (world slabs of `slab` doubles), (3) the gather/solve kernel reads the panel from `recv` instead of the tiles.
 struct RowList { int32_t m; int32_t j[64]; };      // landmark-block rows (2 * landmark index) of one prefetch
 
-int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm);
 // base row-panels of m <= 64 landmarks (0-based indices idx) into send + q * slab, one launch
 hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, int64_t n_mm, double *send, int64_t slab,
                                 int storage, hipStream_t s);
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
                            hipStream_t s);
+// device-resident measure loop on a shard: the row-panel of the landmark the DEVICE's association names (dl.parts_in); j, the host
+// mirror's prediction, only when the winners name nothing inside the state
+hipError_t launch_rowpanel_dev(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
+                               hipStream_t s, const DevLoopArgs &dl);
 // recv: `world` contributions `rank_stride` doubles apart; this correction's row-panel starts `offset` doubles into
 // each; patched: the pending pairs are already applied to it (k_rowpanel) -- otherwise the gather applies them
+// dl != nullptr (device-resident measure loop on a shard): as launch_gather_devloop, on the exchanged row-panel
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
-                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s);
+                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s,
+                                 const DevLoopArgs *dl = nullptr);
 // tiles -= sum_{i < npairs} K_i G_i (in slot order) over the work list (I,J pairs, device array) of `nwork` owned
 // lower-triangle tiles: ONE pass over P for npairs update-steps
 // work_xcd / xcd_len: the same tiles as 8 per-XCD streams (stream x = work_xcd[x*xcd_len ..), padded with (-1,-1)),

@@ -501,16 +501,37 @@ struct PanelView {
     }
 };
 
+// chunks (of T columns) of landmark row j's panel that this shard owns: chunk k comes from tile (I_j, k) or (k, I_j), owner (I_j + k) mod world
+__host__ __device__ inline int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm) {
+    const int64_t nt = (n_mm + tm.T - 1) >> tm.shift;
+    const int64_t Ij = j >> tm.shift;
+    const int64_t k0 = ((tm.rank - Ij) % tm.world + tm.world) % tm.world;
+    return k0 >= nt ? 0 : (nt - k0 + tm.world - 1) / tm.world;
+}
+
 constexpr int kMaxPending = 128;       // 2 * max cfg.batch: pairs of an in-flight flush + pairs recorded since (LDS staging bound)
 
 // Each shard copies the chunks of M it owns (canonical lower-triangle entries, patched with the pending pairs in
 // slot order exactly like the unsharded gather does) into its send slab.
-template <typename TS>
+// kDev (device-resident measure loop on a shard): the landmark is the arg-min over the association's per-workgroup winners
+// (dl.parts_in), reduced by every wavefront itself exactly as k_gather<.., kDev> does a launch later -- j only when the winners name
+// nothing inside the state; the number of chunks this shard owns follows from the landmark's tile row and is recomputed here (the
+// launcher sized the grid for the most any tile row gives).
+template <typename TS, bool kDev = false>
 __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int pstart, int npend,
-                                                     double *__restrict__ send, int64_t nchunks_local) {
+                                                     double *__restrict__ send, int64_t nchunks_local,
+                                                     typename DevLoopParam<kDev>::type dl) {
     __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
     const TileMap &tm = st.tm;
     const TS *__restrict__ tiles = (const TS *)st.tiles;
+    if constexpr (kDev) {
+        double dll;
+        int dix;
+        reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, threadIdx.x & 63, dll, dix);
+        dix = __builtin_amdgcn_readfirstlane(dix);
+        if (dix >= 0 && 2 * (int64_t)dix < n_mm) j = 2 * (int64_t)dix;
+        nchunks_local = rowpanel_local_chunks(tm, j, n_mm);
+    }
     for (int e = threadIdx.x; e < 4 * npend; e += kBlock) {
         const int i = e >> 2, which = e & 3;
         const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
@@ -630,7 +651,7 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 constexpr int kFuseMaxRows = 48;                     // landmark-block rows (24 landmarks) up to which the fused form is used (beyond: slower than two launches)
 constexpr int kFuseElems = kFuseMaxRows * kFuseMaxRows / 256;     // elements of the block per column lane, all in flight together
 
-// kDev (device-resident measure loop, unsharded): the corrected landmark is not a kernel argument but the arg-min over the
+// kDev (device-resident measure loop): the corrected landmark is not a kernel argument but the arg-min over the
 // per-workgroup winners of this observation's association (dl.parts_in), reduced redundantly by every wavefront; and the NEXT
 // observation's association (Correspondence.m:49-87: per-landmark phi_k, Mahalanobis + signature cost, thresholded arg-min) is
 // evaluated in the epilogue by the column lanes, from the values this correction has just produced -- x', strip', Prr', the
@@ -639,7 +660,7 @@ constexpr int kFuseElems = kFuseMaxRows * kFuseMaxRows / 256;     // elements of
 template <typename TS, bool kSharded, bool kPredict, bool kFused = false, bool kDev = false>
 __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArgs a, PanelView pv, PredictArgs pa,
                                                          typename DevLoopParam<kDev>::type dl) {
-    static_assert(!kDev || (!kSharded && !kFused), "the device loop drives the plain unsharded gather");
+    static_assert(!kDev || !kFused, "the device loop never drives the small-map fused form");
     __shared__ double pss[24];
     __shared__ SmallSolve sol;
     __shared__ PredictSmall ps;
@@ -672,6 +693,7 @@ __global__ __launch_bounds__(kGatherBlock) void k_gather(DevState st, CorrectArg
         reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, lane, dll, dix);
         dix = __builtin_amdgcn_readfirstlane(dix);
         if (dix >= 0 && 2 * (int64_t)dix < a.n_mm) j = 2 * (int64_t)dix;       // otherwise a.j: the launch stays inside the state
+        if constexpr (kSharded) pv.Ij = j >> st.tm.shift;                       // (k_rowpanel<.., kDev> laid the panel out for this landmark)
         if (blockIdx.x == 0 && tid == kGatherCols + 128) store_partial(dl.rec, dll, dix, dl.seq_rec);   // BEARING lane 0: it has slack
     }
 
@@ -1847,21 +1869,26 @@ hipError_t launch_gather_devloop(const DevState &st, const CorrectArgs &a, const
     return hipGetLastError();
 }
 
-int64_t rowpanel_local_chunks(const TileMap &tm, int64_t j, int64_t n_mm) {
-    const int64_t nt = ekf_tiles_for(n_mm, tm.T);
-    const int64_t Ij = j >> tm.shift;
-    const int64_t k0 = ((tm.rank - Ij) % tm.world + tm.world) % tm.world;
-    return k0 >= nt ? 0 : (nt - k0 + tm.world - 1) / tm.world;
-}
-
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
                            hipStream_t s) {
     const int64_t nloc = rowpanel_local_chunks(st.tm, j, n_mm);
     if (nloc == 0) return hipSuccess;
     const int64_t grid = cdiv(nloc * st.tm.T, kBlock);
     EKF_STORAGE_DISPATCH(storage,
-        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc),
-        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc));
+        hipLaunchKernelGGL(k_rowpanel<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc, NoDevLoop{}),
+        hipLaunchKernelGGL(k_rowpanel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, nloc, NoDevLoop{}));
+    return hipGetLastError();
+}
+
+hipError_t launch_rowpanel_dev(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
+                               hipStream_t s, const DevLoopArgs &dl) {
+    if (!dl.parts_in || dl.nblk_in < 1) return hipErrorInvalidValue;
+    const int64_t nt = ekf_tiles_for(n_mm, st.tm.T);
+    const int64_t most = (nt + st.tm.world - 1) / st.tm.world;           // what the tile row with this shard's first chunk at k = 0 gives
+    const int64_t grid = cdiv(most * st.tm.T, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL((k_rowpanel<double, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, (int64_t)0, dl),
+        hipLaunchKernelGGL((k_rowpanel<float, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, (int64_t)0, dl));
     return hipGetLastError();
 }
 
@@ -1883,13 +1910,21 @@ hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, i
 }
 
 hipError_t launch_gather_sharded(const DevState &st, const CorrectArgs &a, const PredictArgs *fused_predict, const double *recv,
-                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s) {
+                                 int64_t rank_stride, int64_t offset, bool patched, int storage, hipStream_t s, const DevLoopArgs *dl) {
     const int64_t cols = ekf_tiles_for(a.n_mm, st.tm.T) * st.tm.T;
     const int64_t grid = cdiv(cols, kGatherCols);
     PanelView pv;
     pv.recv = recv; pv.slab = rank_stride; pv.offset = offset; pv.Ij = a.j >> st.tm.shift; pv.patched = patched ? 1 : 0;
     PredictArgs pa = {};
     if (fused_predict) pa = *fused_predict;
+    if (dl) {
+        if (!dl->parts_in || !dl->rec || dl->nblk_in < 1 || a.n_mm < 2) return hipErrorInvalidValue;
+#define EKF_GD(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_, false, true>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa, *dl)
+        if (storage == 0) { if (fused_predict) EKF_GD(double, true); else EKF_GD(double, false); }
+        else              { if (fused_predict) EKF_GD(float, true); else EKF_GD(float, false); }
+#undef EKF_GD
+        return hipGetLastError();
+    }
 #define EKF_G(TS_, PRED_) hipLaunchKernelGGL((k_gather<TS_, true, PRED_>), dim3((unsigned)grid), dim3(kGatherBlock), 0, s, st, a, pv, pa, NoDevLoop{})
     if (storage == 0) { if (fused_predict) EKF_G(double, true); else EKF_G(double, false); }
     else              { if (fused_predict) EKF_G(float, true); else EKF_G(float, false); }

@@ -183,6 +183,53 @@ class ShardGroup:
                 np.testing.assert_array_equal(a, b)
         return res[0]
 
+    def measure(self, observed_LL, u, lm_index, lm_loc):
+        """EKF_SLAM.measure / EKF_SLAM_UC.measure on the group: ekf_measure on every shard, ONE HOST THREAD PER SHARD, the
+        exchanges in the middle of its loop through the hook of transport (d) (include/ekfslam.h): every thread arrives at a
+        barrier with its contribution queued, thread 0 runs ekf_exchange_local over all handles, a second barrier releases
+        them.  (The library calls release the GIL; the hook re-enters Python only for the two barrier waits.)"""
+        import threading
+        world = self.world
+        bar = threading.Barrier(world)
+        xrc = [0]
+        errs = [None] * world
+
+        def make_hook(r):
+            def hook(_ctx):
+                try:
+                    bar.wait()
+                    if r == 0:
+                        xrc[0] = self.lib.ekf_exchange_local(self._harr, world)
+                    bar.wait()
+                    return int(xrc[0])
+                except threading.BrokenBarrierError:
+                    return 1
+            return L.EXCHANGE_HOOK(hook)
+
+        hooks = [make_hook(r) for r in range(world)]
+        for e, hk in zip(self.shards, hooks):
+            self._chk(e, self.lib.ekf_exchange_set_hook(e.h, ctypes.cast(hk, ctypes.c_void_p), None))
+
+        def run(r):
+            try:
+                self.shards[r].measure(observed_LL, u, lm_index, lm_loc)
+            except BaseException as ex:  # noqa: BLE001 -- reported by the caller's thread below
+                errs[r] = ex
+                bar.abort()                                           # the other shards' hooks return an error instead of waiting forever
+
+        try:
+            ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        finally:
+            for e in self.shards:
+                self.lib.ekf_exchange_set_hook(e.h, None, None)
+        for ex in errs:
+            if ex is not None:
+                raise ex
+
     def set_params(self, **kw):
         for e in self.shards:
             e.set_params(**kw)

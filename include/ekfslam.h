@@ -201,10 +201,16 @@ int32_t ekf_hint_next(ekf_handle *h, int64_t idx);
  *   (b) ekf_correct_begin, the caller's own all-gather over the device buffers of ekf_exchange_info (e.g.
  *       torch.distributed on buffers given through ekf_exchange_set_buffers), ekf_correct_finish;
  *   (c) ekf_exchange_local: one host thread driving every shard of the filter in ONE process (the way a
- *       MATLAB host would): begin on all handles, ekf_exchange_local, finish on all handles. */
+ *       MATLAB host would): begin on all handles, ekf_exchange_local, finish on all handles;
+ *   (d) ekf_exchange_set_hook: the caller's all-gather as a callback, run wherever (a) would run ncclAllGather -- inside
+ *       ekf_correct, ekf_prefetch_rows and, which (b) and (c) cannot do, in the middle of ekf_measure's loop.  The
+ *       hook finds the handle between begin and finish (ekf_exchange_info names buffers and count) and returns 0 or
+ *       an error; with one host thread per shard it is a barrier, ekf_exchange_local on one thread, a barrier
+ *       (ekf_slam_amd/sharding.py: ShardGroup.measure). */
 typedef struct ekf_comm_id { char internal[128]; } ekf_comm_id;   /* == ncclUniqueId */
 int32_t ekf_comm_unique_id(ekf_comm_id *id);                      /* rank 0 creates it, the host broadcasts it */
 int32_t ekf_comm_init(ekf_handle *h, const ekf_comm_id *id);      /* collective over all shards */
+int32_t ekf_exchange_set_hook(ekf_handle *h, int32_t (*hook)(void *ctx), void *ctx);   /* hook == NULL removes it */
 int32_t ekf_correct_begin(ekf_handle *h, const double z[2], const double R[4], int64_t idx);
 int32_t ekf_correct_finish(ekf_handle *h);
 /* Latency hiding for hosts that know which landmarks the next corrections touch (a scan's observation list):

@@ -41,12 +41,27 @@ def main():
     ap.add_argument("--verified", action="store_true",
                     help="cfg.device_assoc = 2: k_associate runs for every observation, the host dispatches on its mirror's decision "
                          "without waiting and verifies every device decision before measure() returns")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the SHARDED code path on this one GPU (cfg.force_sharded, the library's own 1-rank RCCL communicator): per "
+                         "correction k_rowpanel<kDev> -> ncclAllGather -> k_gather<sharded, kDev>; what a shard's measure() loop costs")
     args = ap.parse_args()
     from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
     from ekf_slam_amd.world import SyntheticLandmark, make_run
     N = args.landmarks
     _, run = make_run(N, 20260102, 2 + args.steps, policy="nearest", m=args.m)
-    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=(0 if args.host_decision else 2 if args.verified else 1 if args.waited else 3))
+    shard_kw = {"force_sharded": 1} if args.force_sharded else {}
+
+    def attach(engine):
+        if args.force_sharded:
+            import ctypes
+            from ekf_slam_amd import _lib as L_
+            raw = ctypes.create_string_buffer(L_.EKF_COMM_ID_BYTES)
+            if L_.lib().ekf_comm_unique_id(raw) != 0:
+                sys.exit("bench_config2.py: --force-sharded needs librccl (ekf_comm_unique_id failed)")
+            engine.comm_init(raw.raw)
+
+    e = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=(0 if args.host_decision else 2 if args.verified else 1 if args.waited else 3), **shard_kw)
+    attach(e._e)
     lm = Landmark('SYNTHETIC')
     t0 = time.perf_counter()
     for u, scan in run[:2]:                      # warm-up sweep: appends every landmark
@@ -67,7 +82,8 @@ def main():
     # 35-70 ms stall (scripts/probe_queue.py) -- several times this benchmark's whole timed region.  Burn it on a throw-away engine of
     # the same configuration that replays the first scans from the same state.
     if not args.no_conditioning:
-        warm = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=int(eng.cfg.device_assoc))
+        warm = EKF_SLAM_UC(capacity=N, tile=args.tile, batch=args.batch, async_flush=args.async_flush, device_assoc=int(eng.cfg.device_assoc), **shard_kw)
+        attach(warm._e)
         warm.x, warm.s, warm.P = e.x, e.s, e.P
         for rep in range(3):
             for u, obs, idx, loc in feeds[:64]:
@@ -104,6 +120,7 @@ def main():
            "config": {"workload": "configs[1]: %d landmarks, unknown correspondence (EKF_SLAM_UC.m + Correspondence.m), F64; "
                                   "iteration = predict + measure() over the %d nearest landmarks" % (N, args.m),
                       "deferred_batch": args.batch, "async_flush": args.async_flush, "tile": args.tile, "warmup_sweep_s": t_sweep,
+                      "force_sharded": bool(args.force_sharded),
                       "device_association": ("host mirror" if args.host_decision else "device, verified after dispatch" if args.verified
                                              else "device, waited for" if args.waited else
                                              "device-resident loop: decision produced and consumed on the device, no host wait"),

@@ -397,3 +397,79 @@ def test_hinted_pass_extracts_the_next_row_panel(world, tile, storage):
     Ps = sh.get_P()
     np.testing.assert_array_equal(Ps, one.get_P())
     sh.close(); one.close()
+
+
+@pytest.mark.parametrize("world,tile,batch", [(2, 16, 1), (4, 16, 4), (8, 16, 8), (2, 64, 8), (3, 32, 24)])
+def test_device_resident_measure_loop_on_shards(world, tile, batch):
+    """EKF_SLAM_UC.measure (EKF_SLAM_UC.m:107-151) on a ShardGroup with cfg.device_assoc = 3, the default: every shard runs the
+    device-resident loop -- k_associate for a scan's first row, then per correction k_rowpanel<kDev> (the row-panel of the landmark the
+    DEVICE names) -> all-gather -> k_gather<sharded, kDev> (whose epilogue scores the next observation) -- one host thread per shard,
+    the exchanges through the hook of transport (d).  Bit-identical to the unsharded device loop, scan after scan."""
+    from ekf_slam_amd import Engine, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    from ekf_slam_amd.slam import Landmark
+    from ekf_slam_amd.world import make_run
+    N, M, ITERS = 150, 6, 14
+    _, run = make_run(N, 20260110 + world, 2 + ITERS, policy="nearest", m=M)
+    kw = dict(mode="uc", capacity=N, tile=tile, batch=batch)
+    one, g = Engine(**kw), ShardGroup(world, **kw)
+    assert one.cfg.device_assoc == 3 and all(e.cfg.device_assoc == 3 for e in g.shards)
+    for kid in (L.EKF_KERNEL_ASSOCIATE, L.EKF_KERNEL_ROWPANEL, L.EKF_KERNEL_GATHER):
+        g.shards[-1].timing_enable(kid, True, launches=4096)
+    lm1, lmg = Landmark('SYNTHETIC'), Landmark('SYNTHETIC')
+    corrections = scans = 0
+    for t, (u, scan) in enumerate(run):
+        one.predict(u); g.predict(u)
+        n_before = one.N
+        for eng, lm in ((one, lm1), (g, lmg)):
+            obs = lm.getLandmark(scan, eng.get_x())
+            idx, loc = lm.landmarkObj.table()
+            eng.measure(obs, u, idx, loc)
+        corrections += len(scan) - (one.N - n_before)
+        scans += 1
+        assert g.N == one.N
+        np.testing.assert_array_equal(g.get_x(), one.get_x())
+    assert one.N == N
+    one.flush(); g.flush()
+    np.testing.assert_array_equal(g.get_P(), one.get_P())
+    np.testing.assert_allclose(g.digest(), one.digest(), rtol=1e-12)
+    # the loop ran on the shards: k_associate launches (the host-mirror path launches none when w_pos == 0), and one device-named
+    # extraction + one gather per correction
+    n_as, _ = g.shards[-1].timing_read(L.EKF_KERNEL_ASSOCIATE)
+    n_rp, _ = g.shards[-1].timing_read(L.EKF_KERNEL_ROWPANEL)
+    n_ga, _ = g.shards[-1].timing_read(L.EKF_KERNEL_GATHER)
+    assert n_as >= 1 and n_rp == corrections and n_ga == corrections, (n_as, n_rp, n_ga, corrections)
+    g.close(); one.close()
+
+
+def test_device_resident_measure_loop_on_a_one_rank_communicator():
+    """The same loop through the library's own RCCL communicator (transport (a)), one rank on this GPU (cfg.force_sharded):
+    bit-identical to the unsharded handle."""
+    import ctypes
+    from ekf_slam_amd import Engine, _lib as L
+    from ekf_slam_amd.slam import Landmark
+    from ekf_slam_amd.world import make_run
+    raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+    if L.lib().ekf_comm_unique_id(raw) != 0:
+        pytest.skip("librccl not loadable")
+    N, M, ITERS = 300, 8, 20
+    _, run = make_run(N, 20260117, 2 + ITERS, policy="nearest", m=M)
+    kw = dict(mode="uc", capacity=N, tile=32, batch=8)
+    one, sh = Engine(**kw), Engine(force_sharded=1, **kw)
+    sh.comm_init(raw.raw)
+    sh.timing_enable(L.EKF_KERNEL_EXCHANGE, True, launches=4096)
+    lms = [Landmark('SYNTHETIC'), Landmark('SYNTHETIC')]
+    corrections = 0
+    for u, scan in run:
+        n_before = one.N
+        for eng, lm in zip((one, sh), lms):
+            eng.predict(u)
+            obs = lm.getLandmark(scan, eng.get_x())
+            idx, loc = lm.landmarkObj.table()
+            eng.measure(obs, u, idx, loc)
+        corrections += len(scan) - (one.N - n_before)
+    one.flush(); sh.flush()
+    np.testing.assert_array_equal(sh.get_x(), one.get_x())
+    np.testing.assert_array_equal(sh.get_P(), one.get_P())
+    assert corrections >= ITERS * M and sh.timing_read(L.EKF_KERNEL_EXCHANGE)[0] == corrections      # one ncclAllGather per correction
+    one.close(); sh.close()
