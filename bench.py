@@ -327,10 +327,16 @@ def main():
             m = chunk["m"]
             if lookahead and sharded and batch > 1:
                 # a host that knows which landmarks the next `batch` corrections touch fetches their base row-panels
-                # in ONE all-gather (ekf_prefetch_rows); the corrections then need no exchange of their own
+                # in ONE all-gather (ekf_prefetch_rows); the corrections then need no exchange of their own.  With the
+                # library's own communicator the batch AFTER is announced as well (ekf_prefetch_next): its row-panels are
+                # extracted in front of this batch's pass as that pass will leave them, and exchanged beside it
+                announce = e._host_exchange is None
                 for b0 in range(0, m, batch):
                     b1 = min(m, b0 + batch)
-                    e.prefetch_rows(sorted(set(chunk["k"][b0:b1])))
+                    if b0 == 0 or not announce:
+                        e.prefetch_rows(sorted(set(chunk["k"][b0:b1])))
+                    if announce and b1 < m:
+                        e.prefetch_next(sorted(set(chunk["k"][b1:min(m, b1 + batch)])))
                     for i in range(b0, b1):
                         e.step_raw(chunk, i)
             else:
@@ -519,8 +525,9 @@ def main():
         if dfr2 is not None:
             out["deferred_b%d" % batch2] = public(dfr2, "as `deferred`, at cfg.batch = %d" % batch2)
         if look is not None:
-            out["deferred_lookahead"] = public(look, "as `deferred`, with the landmarks of the next %d corrections announced "
-                                                     "(ekf_prefetch_rows): one all-gather per batch" % batch)
+            out["deferred_lookahead"] = public(look, "as `deferred`, with the landmarks of the next %d corrections announced: one "
+                                                     "all-gather per batch%s" % (batch, " (ekf_prefetch_rows)" if look["transport"] != "rccl-native" else
+                                                     ", issued in front of the previous batch's pass and run beside it (ekf_prefetch_next)"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(N, x, s, d, U, steps[args.warmup:])
             # SURVEY.md 8d asks for both restatements beside the GPU figure: [0] the primary above, [1] the literal-dense one

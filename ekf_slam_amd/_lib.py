@@ -62,6 +62,7 @@ SIGNATURES = {
     "ekf_correct_begin": (_i32, [_vp, _dp, _dp, _i64]),
     "ekf_correct_finish": (_i32, [_vp]),
     "ekf_prefetch_rows": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),
+    "ekf_prefetch_next": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),
     "ekf_prefetch_begin": (_i32, [_vp, ctypes.POINTER(_i64), _i32]),
     "ekf_prefetch_finish": (_i32, [_vp]),
     "ekf_exchange_info": (_i32, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64),

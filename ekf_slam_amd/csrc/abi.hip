@@ -167,6 +167,12 @@ struct ekf_handle {
     bool nx_valid = false;
     int64_t nx_idx = -1, nx_N = 0;
     void *comm = nullptr;          // ncclComm_t
+    // ekf_prefetch_next: the landmarks of the batch AFTER the current one.  When the current batch completes, their row-panels are
+    // extracted as the pass will leave them (k_rowpanel_next) in front of the pass, and the all-gather runs on xchg_stream beside it.
+    std::vector<int64_t> pn_idx;
+    int64_t pn_N = -1;
+    hipStream_t xchg_stream = nullptr;
+    hipEvent_t ev_pn_ready = nullptr, ev_pn_done = nullptr;
     int32_t (*xhook)(void *) = nullptr;   // ekf_exchange_set_hook: the caller's all-gather, called where the library-owned one would run
     void *xhook_ctx = nullptr;
     KernelTimer timers[EKF_KERNEL_COUNT];
@@ -369,7 +375,8 @@ double *corr_send(const ekf_handle *h, int64_t slab) {
 }
 
 // apply ALL pending pairs to the tiles now, in place on the main stream: ONE pass over P for npend update-steps
-int32_t flush_pending(ekf_handle *h) {
+int32_t exchange_rccl(ekf_handle *h);
+int32_t flush_pending(ekf_handle *h, bool batch_done = false) {
     int32_t rc = retire_inflight(h);
     if (rc) return rc;
     if (h->npend == 0) return EKF_OK;
@@ -378,6 +385,57 @@ int32_t flush_pending(ekf_handle *h) {
     next_pass_direction(h);
     bool extracted = false;
     const int64_t hint = h->hint_idx;
+    // ekf_prefetch_next: the next batch's row-panels, as THIS pass will leave them, are extracted now; their all-gather runs beside the pass
+    bool pn = false, pn_side = false;
+    if (batch_done && !h->pn_idx.empty()) {
+        if (h->sharded && !h->pending && h->pn_N == h->N && (h->comm || h->xhook)) {
+            const int32_t m = (int32_t)h->pn_idx.size();
+            const int64_t slab = slab_for(h, n_mm(h));
+            {
+                TimedLaunch tl(h, EKF_KERNEL_ROWPANEL);
+                HIPCHK(h, launch_rowpanel_next(h->st, h->pn_idx.data(), m, n_mm(h), h->pstart, h->npend, h->send, slab, h->storage, h->stream));
+            }
+            h->pf_valid = false; h->nx_valid = false;
+            h->pf_idx = h->pn_idx; h->pf_m = m; h->pf_slab = slab; h->pf_N = h->N;
+            h->x_count = (int64_t)m * slab;
+            // Where the all-gather runs.  On the handle's stream, in front of the pass: what ships.  On a stream of its own BESIDE the
+            // pass (tuning builds, EKF_PN_SIDE_STREAM=1): built, bit-identical, and on one GPU twice as slow per update-step -- with a
+            // second stream in use every dispatch of the main stream costs ~50 us more on this runtime (the same finding as
+            // cfg.async_flush, profiles/round2_tuning.md 21-22; round4_tuning.md 49).  To be measured again where the all-gather
+            // crosses xGMI and is long enough to be worth hiding.
+            static const int pn_side_stream = ekf_tune_int("EKF_PN_SIDE_STREAM", 0);
+            if (h->comm && !pn_side_stream) {
+                const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->stream);
+                if (r != 0) return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r));
+                HIPCHK(h, hipMemcpyAsync(h->pf_store, h->recv, (size_t)h->x_count * h->cfg.world * sizeof(double), hipMemcpyDeviceToDevice,
+                                         h->stream));
+            } else if (h->comm) {
+                if (!h->xchg_stream) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->xchg_stream, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_pn_ready, hipEventDisableTiming));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_pn_done, hipEventDisableTiming));
+                }
+                HIPCHK(h, hipEventRecord(h->ev_pn_ready, h->stream));
+                HIPCHK(h, hipStreamWaitEvent(h->xchg_stream, h->ev_pn_ready, 0));
+                const int r = g_rccl.AllGather(h->send, h->recv, (size_t)h->x_count, /*ncclDouble*/ 8, h->comm, h->xchg_stream);
+                if (r != 0) return fail(h, EKF_ERR_COMM, g_rccl.GetErrorString(r));
+                HIPCHK(h, hipMemcpyAsync(h->pf_store, h->recv, (size_t)h->x_count * h->cfg.world * sizeof(double), hipMemcpyDeviceToDevice,
+                                         h->xchg_stream));
+                HIPCHK(h, hipEventRecord(h->ev_pn_done, h->xchg_stream));
+                pn_side = true;
+            } else {
+                // transport (d): the caller's all-gather runs on the host's schedule, i.e. in front of the pass
+                h->pending = true; h->pending_kind = 2;
+                rc = exchange_rccl(h);
+                h->pending = false; h->pending_kind = 0;
+                if (rc) return rc;
+                HIPCHK(h, hipMemcpyAsync(h->pf_store, h->recv, (size_t)h->x_count * h->cfg.world * sizeof(double), hipMemcpyDeviceToDevice,
+                                         h->stream));
+            }
+            pn = true;
+        }
+        h->pn_idx.clear();
+    }
     {
         // a sharded handle that was told which landmark the next correction names lets this pass extract that row-panel
         NextRow nx = { -1, nullptr };
@@ -393,8 +451,9 @@ int32_t flush_pending(ekf_handle *h) {
     }
     h->npend = 0;
     h->pstart = 0;
-    h->pf_valid = false;       // the prefetched row-panels were base values of the old tiles
-    h->nx_valid = extracted;
+    h->pf_valid = pn;          // prefetched row-panels were base values of the old tiles -- unless they were extracted as this pass leaves them
+    if (pn_side) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_pn_done, 0));      // whatever follows the pass may read them (and reuse the exchange areas)
+    h->nx_valid = extracted && !pn;
     if (extracted) { h->nx_idx = hint; h->nx_N = h->N; }
     return EKF_OK;
 }
@@ -402,7 +461,7 @@ int32_t flush_pending(ekf_handle *h) {
 // a batch is complete: start its pass over P.  Synchronous engines do it in place; asynchronous ones launch it on the
 // flush stream into the other tile store and keep going.
 int32_t batch_complete(ekf_handle *h) {
-    if (!h->async_flush) return flush_pending(h);
+    if (!h->async_flush) return flush_pending(h, /*batch_done*/ true);
     // Recorded BEFORE the main stream is made to wait for the previous pass (retire_inflight): every pair of this batch has been
     // written and every reader of the store this pass overwrites is queued in front of it -- that is all the new pass depends on
     // (the previous pass precedes it in the flush stream's own order).  Recording it after that wait would chain the passes
@@ -545,6 +604,7 @@ int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const dou
     h->N += 1;
     h->pf_valid = false;
     h->nx_valid = false;
+    h->pn_idx.clear();         // (an announced prefetch spoke of the map before it grew)
     return EKF_OK;
 }
 
@@ -1214,6 +1274,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     for (hipEvent_t e : h->throttle_ev) if (e) hipEventDestroy(e);
     if (h->flush_stream) { hipStreamSynchronize(h->flush_stream); hipStreamDestroy(h->flush_stream); }
+    if (h->xchg_stream) { hipStreamSynchronize(h->xchg_stream); hipStreamDestroy(h->xchg_stream); hipEventDestroy(h->ev_pn_ready); hipEventDestroy(h->ev_pn_done); }
     if (h->ev_xchg) hipEventDestroy(h->ev_xchg);
     if (h->ev_pairs) hipEventDestroy(h->ev_pairs);
     if (h->ev_flushed) hipEventDestroy(h->ev_flushed);
@@ -1503,6 +1564,24 @@ int32_t ekf_prefetch_rows(ekf_handle *h, const int64_t *idx, int32_t m) {
     rc = exchange_rccl(h);
     if (rc) { h->pending = false; return rc; }
     return prefetch_finish(h);
+}
+
+int32_t ekf_prefetch_next(ekf_handle *h, const int64_t *idx, int32_t m) {
+    if (!h || (m > 0 && !idx) || m < 0) return fail(h, EKF_ERR_INVALID_ARG, "prefetch_next: bad argument");
+    if (!h->sharded) return EKF_OK;                  // nothing to exchange on an unsharded handle
+    h->pn_idx.clear();
+    if (m == 0) return EKF_OK;
+    REQUIRE(h, h->batch > 1 && !h->async_flush, EKF_ERR_STATE, "prefetch_next: needs cfg.batch > 1 and a synchronous flush");
+    REQUIRE(h, h->cfg.pass_arith == EKF_ARITH_F64, EKF_ERR_STATE,
+            "prefetch_next: with cfg.pass_arith = EKF_ARITH_F32 the pass's result is not what an extraction in front of it can compute");
+    REQUIRE(h, h->comm != nullptr || h->xhook != nullptr, EKF_ERR_STATE,
+            "prefetch_next: needs the library-owned communicator (ekf_comm_init) or an exchange hook (ekf_exchange_set_hook)");
+    REQUIRE(h, m <= h->batch && m <= 64, EKF_ERR_INVALID_ARG, "prefetch_next: between 1 and min(cfg.batch, 64) landmarks");
+    for (int32_t q = 0; q < m; ++q)
+        REQUIRE(h, idx[q] >= 0 && idx[q] < h->N, EKF_ERR_INDEX, "prefetch_next: landmark index outside the state");
+    h->pn_idx.assign(idx, idx + m);
+    h->pn_N = h->N;
+    return EKF_OK;
 }
 
 int32_t ekf_exchange_info(ekf_handle *h, void **send, void **recv, int64_t *count, int64_t *count_capacity) {

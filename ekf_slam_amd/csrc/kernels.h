@@ -157,6 +157,9 @@ struct RowList { int32_t m; int32_t j[64]; };      // landmark-block rows (2 * l
 // base row-panels of m <= 64 landmarks (0-based indices idx) into send + q * slab, one launch
 hipError_t launch_rowpanel_base(const DevState &st, const int64_t *idx, int m, int64_t n_mm, double *send, int64_t slab,
                                 int storage, hipStream_t s);
+// the row-panels of m <= 64 landmarks as the tiles will hold them after the pass that applies the npend pending pairs, into send + q * slab
+hipError_t launch_rowpanel_next(const DevState &st, const int64_t *idx, int m, int64_t n_mm, int pstart, int npend, double *send,
+                                int64_t slab, int storage, hipStream_t s);
 hipError_t launch_rowpanel(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *send, int storage,
                            hipStream_t s);
 // device-resident measure loop on a shard: the row-panel of the landmark the DEVICE's association names (dl.parts_in); j, the host

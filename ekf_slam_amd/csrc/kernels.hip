@@ -511,27 +511,15 @@ __host__ __device__ inline int64_t rowpanel_local_chunks(const TileMap &tm, int6
 
 constexpr int kMaxPending = 128;       // 2 * max cfg.batch: pairs of an in-flight flush + pairs recorded since (LDS staging bound)
 
-// Each shard copies the chunks of M it owns (canonical lower-triangle entries, patched with the pending pairs in
-// slot order exactly like the unsharded gather does) into its send slab.
-// kDev (device-resident measure loop on a shard): the landmark is the arg-min over the association's per-workgroup winners
-// (dl.parts_in), reduced by every wavefront itself exactly as k_gather<.., kDev> does a launch later -- j only when the winners name
-// nothing inside the state; the number of chunks this shard owns follows from the landmark's tile row and is recomputed here (the
-// launcher sized the grid for the most any tile row gives).
-template <typename TS, bool kDev = false>
-__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int pstart, int npend,
-                                                     double *__restrict__ send, int64_t nchunks_local,
-                                                     typename DevLoopParam<kDev>::type dl) {
-    __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
+// One landmark's row-panel: this shard's chunks of M = P(j:j+1, :) (canonical lower-triangle entries, patched with the npend pending
+// pairs in slot order exactly like the unsharded gather does) into `send`.  `upatch` (LDS) is staged by the caller's whole workgroup.
+// kAsStored: the values as the tiles will hold them AFTER the pass that applies these pairs -- rounded through the storage type (the
+// F64-arithmetic passes over float tiles round once, at the store; F64 tiles: no-op).
+template <typename TS, bool kAsStored>
+__device__ __forceinline__ void rowpanel_row(const DevState &st, int64_t j, int64_t n_mm, int pstart, int npend, double *__restrict__ send,
+                                             int64_t nchunks_local, double2 *upatch) {
     const TileMap &tm = st.tm;
     const TS *__restrict__ tiles = (const TS *)st.tiles;
-    if constexpr (kDev) {
-        double dll;
-        int dix;
-        reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, threadIdx.x & 63, dll, dix);
-        dix = __builtin_amdgcn_readfirstlane(dix);
-        if (dix >= 0 && 2 * (int64_t)dix < n_mm) j = 2 * (int64_t)dix;
-        nchunks_local = rowpanel_local_chunks(tm, j, n_mm);
-    }
     for (int e = threadIdx.x; e < 4 * npend; e += kBlock) {
         const int i = e >> 2, which = e & 3;
         const double *base = (which < 2 ? st.Kp : st.Gp) + (int64_t)ring_slot(pstart, i, st.pcap) * st.pair_stride;
@@ -587,7 +575,40 @@ __global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int
             }
         }
     }
+    if (kAsStored) { m0 = (double)(TS)m0; m1 = (double)(TS)m1; }
     reinterpret_cast<double2 *>(send)[e] = make_double2(m0, m1);
+}
+
+// Each shard copies the chunks of M it owns into its send slab.
+// kDev (device-resident measure loop on a shard): the landmark is the arg-min over the association's per-workgroup winners
+// (dl.parts_in), reduced by every wavefront itself exactly as k_gather<.., kDev> does a launch later -- j only when the winners name
+// nothing inside the state; the number of chunks this shard owns follows from the landmark's tile row and is recomputed here (the
+// launcher sized the grid for the most any tile row gives).
+template <typename TS, bool kDev = false>
+__global__ __launch_bounds__(kBlock) void k_rowpanel(DevState st, int64_t j, int64_t n_mm, int pstart, int npend,
+                                                     double *__restrict__ send, int64_t nchunks_local,
+                                                     typename DevLoopParam<kDev>::type dl) {
+    __shared__ double2 upatch[kMaxPending * 4];     // per pending pair: K_i(j,:), K_i(j+1,:), G_i(:,j), G_i(:,j+1)
+    if constexpr (kDev) {
+        double dll;
+        int dix;
+        reduce_partials_wave(dl.parts_in, dl.nblk_in, dl.seq_in, threadIdx.x & 63, dll, dix);
+        dix = __builtin_amdgcn_readfirstlane(dix);
+        if (dix >= 0 && 2 * (int64_t)dix < n_mm) j = 2 * (int64_t)dix;
+        nchunks_local = rowpanel_local_chunks(st.tm, j, n_mm);
+    }
+    rowpanel_row<TS, false>(st, j, n_mm, pstart, npend, send, nchunks_local, upatch);
+}
+
+// The row-panels of up to 64 landmarks AS THEY WILL BE AFTER THE PASS that applies the npend pending pairs (ekf_prefetch_next: the next
+// batch's prefetch, extracted in front of this batch's pass so that its all-gather runs beside the pass): blockIdx.y picks the landmark.
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_rowpanel_next(DevState st, RowList rows, int64_t n_mm, int pstart, int npend,
+                                                          double *__restrict__ send, int64_t slab) {
+    __shared__ double2 upatch[kMaxPending * 4];
+    const int q = blockIdx.y;
+    const int64_t j = rows.j[q];
+    rowpanel_row<TS, true>(st, j, n_mm, pstart, npend, send + (int64_t)q * slab, rowpanel_local_chunks(st.tm, j, n_mm), upatch);
 }
 
 
@@ -1889,6 +1910,23 @@ hipError_t launch_rowpanel_dev(const DevState &st, int64_t j, int64_t n_mm, int 
     EKF_STORAGE_DISPATCH(storage,
         hipLaunchKernelGGL((k_rowpanel<double, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, (int64_t)0, dl),
         hipLaunchKernelGGL((k_rowpanel<float, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, st, j, n_mm, pstart, npend, send, (int64_t)0, dl));
+    return hipGetLastError();
+}
+
+hipError_t launch_rowpanel_next(const DevState &st, const int64_t *idx, int m, int64_t n_mm, int pstart, int npend, double *send,
+                                int64_t slab, int storage, hipStream_t s) {
+    if (m <= 0) return hipSuccess;
+    if (m > 64 || npend < 0 || npend > kMaxPending) return hipErrorInvalidValue;
+    RowList rows;
+    rows.m = m;
+    for (int q = 0; q < m; ++q) rows.j[q] = (int32_t)(2 * idx[q]);
+    const int64_t nt = st.tm.tiles_for(n_mm);
+    const int64_t max_chunks = (nt + st.tm.world - 1) / st.tm.world;
+    if (max_chunks == 0) return hipSuccess;
+    const int64_t grid = cdiv(max_chunks * st.tm.T, kBlock);
+    EKF_STORAGE_DISPATCH(storage,
+        hipLaunchKernelGGL(k_rowpanel_next<double>, dim3((unsigned)grid, (unsigned)m), dim3(kBlock), 0, s, st, rows, n_mm, pstart, npend, send, slab),
+        hipLaunchKernelGGL(k_rowpanel_next<float>, dim3((unsigned)grid, (unsigned)m), dim3(kBlock), 0, s, st, rows, n_mm, pstart, npend, send, slab));
     return hipGetLastError();
 }
 

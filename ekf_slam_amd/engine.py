@@ -153,6 +153,14 @@ class Engine:
             return
         self._check(self.lib.ekf_prefetch_rows(self.h, arr, len(idx0_list)))
 
+    def prefetch_next(self, idx0_list):
+        """Announce the landmarks of the batch AFTER the current one (ekf_prefetch_next): extracted in front of the current batch's
+        pass as that pass will leave them, exchanged beside it.  Library-owned communicator or exchange hook only."""
+        if self._host_exchange is not None:
+            raise L.EkfError(L.EKF_ERR_STATE, "prefetch_next: the host-run all-gather cannot run inside the library's flush")
+        arr = (ctypes.c_int64 * len(idx0_list))(*[int(i) for i in idx0_list])
+        self._check(self.lib.ekf_prefetch_next(self.h, arr, len(idx0_list)))
+
     def prefetch_begin(self, idx0_list):
         arr = (ctypes.c_int64 * len(idx0_list))(*[int(i) for i in idx0_list])
         self._check(self.lib.ekf_prefetch_begin(self.h, arr, len(idx0_list)))

@@ -183,11 +183,12 @@ class ShardGroup:
                 np.testing.assert_array_equal(a, b)
         return res[0]
 
-    def measure(self, observed_LL, u, lm_index, lm_loc):
-        """EKF_SLAM.measure / EKF_SLAM_UC.measure on the group: ekf_measure on every shard, ONE HOST THREAD PER SHARD, the
-        exchanges in the middle of its loop through the hook of transport (d) (include/ekfslam.h): every thread arrives at a
-        barrier with its contribution queued, thread 0 runs ekf_exchange_local over all handles, a second barrier releases
-        them.  (The library calls release the GIL; the hook re-enters Python only for the two barrier waits.)"""
+    def run_threaded(self, fn):
+        """fn(shard) on every shard, ONE HOST THREAD PER SHARD, with the exchange hook of transport (d) (include/ekfslam.h) set:
+        wherever a library call needs an all-gather -- ekf_correct, ekf_prefetch_rows, the middle of ekf_measure's loop, a batch's
+        pass with an announced prefetch (ekf_prefetch_next) -- every thread arrives at a barrier with its contribution queued, thread
+        0 runs ekf_exchange_local over all handles, a second barrier releases them.  (The library calls release the GIL; the hook
+        re-enters Python only for the two barrier waits.)"""
         import threading
         world = self.world
         bar = threading.Barrier(world)
@@ -212,7 +213,7 @@ class ShardGroup:
 
         def run(r):
             try:
-                self.shards[r].measure(observed_LL, u, lm_index, lm_loc)
+                fn(self.shards[r])
             except BaseException as ex:  # noqa: BLE001 -- reported by the caller's thread below
                 errs[r] = ex
                 bar.abort()                                           # the other shards' hooks return an error instead of waiting forever
@@ -229,6 +230,10 @@ class ShardGroup:
         for ex in errs:
             if ex is not None:
                 raise ex
+
+    def measure(self, observed_LL, u, lm_index, lm_loc):
+        """EKF_SLAM.measure / EKF_SLAM_UC.measure on the group: ekf_measure on every shard (run_threaded)."""
+        self.run_threaded(lambda e: e.measure(observed_LL, u, lm_index, lm_loc))
 
     def set_params(self, **kw):
         for e in self.shards:

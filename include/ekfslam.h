@@ -219,6 +219,13 @@ int32_t ekf_correct_finish(ekf_handle *h);
  * rewritten (a flush) or the map grows.  ekf_prefetch_rows = begin + ncclAllGather + finish (transport (a)); begin /
  * finish bracket the caller's all-gather for transports (b) and (c).  No-op on an unsharded handle. */
 int32_t ekf_prefetch_rows(ekf_handle *h, const int64_t *idx, int32_t m);
+/* The same for the batch AFTER the current one, announced while the current one is still being recorded: when the current batch
+ * completes, the row-panels of these landmarks are extracted AS THE BATCH'S PASS WILL LEAVE THEM (pending pairs applied in slot
+ * order, rounded through the storage type -- bit for bit what a prefetch after the pass would read) and exchanged in front of the
+ * pass: the next batch starts with its prefetch in place, and the exchange no longer depends on the pass (a build that runs it on a
+ * stream of its own beside the pass exists behind a tuning switch; on one GPU it is slower, abi.hip: flush_pending).  Dropped if the map grows before the batch completes.  Needs cfg.batch > 1, a synchronous
+ * flush and cfg.pass_arith = EKF_ARITH_F64 (EKF_ERR_STATE otherwise); m = 0 withdraws an announcement; no-op on an unsharded handle. */
+int32_t ekf_prefetch_next(ekf_handle *h, const int64_t *idx, int32_t m);
 int32_t ekf_prefetch_begin(ekf_handle *h, const int64_t *idx, int32_t m);
 int32_t ekf_prefetch_finish(ekf_handle *h);
 /* Device pointers of the exchange: send area (*count doubles valid for the pending begin) and receive area (world

@@ -473,3 +473,68 @@ def test_device_resident_measure_loop_on_a_one_rank_communicator():
     np.testing.assert_array_equal(sh.get_P(), one.get_P())
     assert corrections >= ITERS * M and sh.timing_read(L.EKF_KERNEL_EXCHANGE)[0] == corrections      # one ncclAllGather per correction
     one.close(); sh.close()
+
+
+def _lookahead_run(eng_or_group, steps, batch, announce, threaded):
+    """predict + correct over `steps` in batches; the landmarks of a batch are prefetched -- by ekf_prefetch_rows at the batch's start,
+    or (announce) by ekf_prefetch_next during the batch before."""
+    def drive(e):
+        nb = (len(steps) + batch - 1) // batch
+        lists = [sorted(set(k for (_, _, _, k) in steps[b * batch:(b + 1) * batch])) for b in range(nb)]
+        for b in range(nb):
+            if b == 0 or not announce:
+                e.prefetch_rows(lists[b])
+            if announce and b + 1 < nb:
+                e.prefetch_next(lists[b + 1])
+            for (u, z, R, k) in steps[b * batch:(b + 1) * batch]:
+                e.predict(u)
+                e.correct(z, R, k)
+        e.flush()
+    if threaded:
+        eng_or_group.run_threaded(drive)
+    else:
+        drive(eng_or_group)
+
+
+@pytest.mark.parametrize("world,tile,batch,storage", [(2, 16, 4, "f64"), (4, 32, 8, "f64"), (3, 16, 20, "f32"), (1, 32, 8, "f64"), (1, 64, 20, "f32")])
+def test_prefetch_announced_before_the_pass_is_bit_identical(world, tile, batch, storage):
+    """ekf_prefetch_next: the next batch's row-panels extracted in front of the current batch's pass AS THAT PASS WILL LEAVE THEM, their
+    all-gather beside the pass (world 1: the library's own 1-rank RCCL communicator and its exchange stream; worlds 2-4: one host
+    thread per shard, the exchange hook).  Same bits as prefetching after the pass, and as the unsharded deferred engine."""
+    import ctypes
+    from ekf_slam_amd import Engine, _lib as L
+    from ekf_slam_amd.sharding import ShardGroup
+    import bench
+    N = 200
+    w, x, s, d, U = bench.make_state(N, 20260120 + world)
+    steps = bench.make_steps(w, N, 5 * batch + 3, [.01, 5.0])
+    kw = dict(capacity=N, tile=tile, batch=batch, storage=storage)
+    one = Engine(**kw)
+    one.load_lowrank_state(x, s, d, U)
+    for (u, z, R, k) in steps:
+        one.predict(u); one.correct(z, R, k)
+    one.flush()
+    results = []
+    for announce in (False, True):
+        if world == 1:
+            raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+            if L.lib().ekf_comm_unique_id(raw) != 0:
+                pytest.skip("librccl not loadable")
+            g = Engine(force_sharded=1, **kw)
+            g.comm_init(raw.raw)
+        else:
+            g = ShardGroup(world, **kw)
+        g.load_lowrank_state(x, s, d, U)
+        last = g if world == 1 else g.shards[-1]
+        last.timing_enable(L.EKF_KERNEL_ROWPANEL, True, launches=4096)
+        _lookahead_run(g, steps, batch, announce, threaded=world > 1)
+        results.append((g.get_x(), g.get_P(), last.timing_read(L.EKF_KERNEL_ROWPANEL)[0]))
+        g.close()
+    for (xg, Pg, _) in results:
+        np.testing.assert_array_equal(xg, one.get_x())
+        np.testing.assert_array_equal(Pg, one.get_P())
+    # one extraction launch per batch either way (k_rowpanel_base at the batch's start / k_rowpanel_next in front of the pass): every
+    # correction found its landmark prefetched
+    nb = (len(steps) + batch - 1) // batch
+    assert results[0][2] == nb and results[1][2] == nb, (results[0][2], results[1][2], nb)
+    one.close()
