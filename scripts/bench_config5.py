@@ -120,7 +120,7 @@ def main():
     pipe_frac = flops / (avg_ms * 1e-3) / pipe_peak
     bound = "mfma" if pipe_frac > hbm_frac else "hbm"
     pmc = load_pmc(N0, args.batch, args.storage)
-    if pmc is not None and pmc.get("kernel") and pmc["kernel"] not in kernel_full:
+    if pmc is not None and pmc.get("kernel") and pmc["kernel"].split("<")[0] != kernel_full.split("<")[0]:
         pmc = None                                            # measured on another kernel: does not describe these launches
     roof = {"bound": bound,
             "achieved": flops / (avg_ms * 1e-3) / 1e12 if bound == "mfma" else b_alg / (avg_ms * 1e-3) / 1e9,
