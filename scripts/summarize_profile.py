@@ -47,6 +47,11 @@ for (kname, grid), (f_kib, nf) in sorted(fetch.items(), key=lambda kv: kv[0][1])
     w_kib, nw = write[(kname, grid)]
     short = next((k for k in ("k_flush_mfma", "k_flush_lds", "k_downdate_w", "k_downdate") if k in kname), kname[:40])
     pairs = 1 if short.startswith("k_downdate") else dbatch           # the immediate leg launches the one-pair kernel
+    for key in ("deferred", ) + tuple(k for k in bench if k.startswith("deferred_b")):
+        # several deferred legs (batch 20, batch 32): the leg whose launcher reported this kernel instance
+        inst = bench.get(key, {}).get("roofline", {}).get("kernel", "")
+        if inst and inst.replace(" ", "").rstrip(">") in kname.replace(" ", ""):
+            pairs = bench[key]["deferred_batch"]
     rec = {"kernel": short, "kernel_instance": kname.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0],
            "grid_size": grid, "landmarks": N, "tile": tile, "batch": pairs,
            "FETCH_SIZE_KiB_avg": f_kib, "fetch_dispatches": nf, "WRITE_SIZE_KiB_avg": w_kib, "write_dispatches": nw,
@@ -56,20 +61,20 @@ for (kname, grid), (f_kib, nf) in sorted(fetch.items(), key=lambda kv: kv[0][1])
     legs.append(rec)
 mf = glob.glob(os.path.join(src, "pmc_mfma", "*", "*_counter_collection.csv"))
 if mf:
-    busy, act = {}, {}
+    busy, act = {}, {}                               # per kernel instance: dispatch -> counter value
     for r in csv.DictReader(open(mf[0])):
         if "k_flush_mfma" in r["Kernel_Name"]:
             d = busy if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES" else act if r["Counter_Name"] == "GRBM_GUI_ACTIVE" else None
             if d is not None:
-                d.setdefault(r["Dispatch_Id"], 0.0)
-                d[r["Dispatch_Id"]] += float(r["Counter_Value"])
-    if busy and act:
-        b = sum(busy.values()) / len(busy)
-        a = sum(act.values()) / len(act)
-        for leg in legs:
-            if leg["kernel"] == "k_flush_mfma":
+                dd = d.setdefault(r["Kernel_Name"], {})
+                dd[r["Dispatch_Id"]] = dd.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    for leg in legs:
+        for kname in busy:
+            if leg["kernel"] == "k_flush_mfma" and leg["kernel_instance"] in kname.replace("(anonymous namespace)::", "") and kname in act:
+                bq = sum(busy[kname].values()) / len(busy[kname])
+                aq = sum(act[kname].values()) / len(act[kname])
                 # busy cycles summed over 1024 SIMDs / active cycles summed over 8 XCDs
-                leg["matrix_pipe_busy"] = (b / 1024.0) / (a / 8.0)
+                leg["matrix_pipe_busy"] = (bq / 1024.0) / (aq / 8.0)
 out = {"correction": "gfx950: FETCH_SIZE x2 (128-B requests tallied at 64 B, 16-B/lane streaming reads); WRITE_SIZE exact "
                      "(MI355X_MICROARCH.md, HBM)",
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py, %s" % tag,
