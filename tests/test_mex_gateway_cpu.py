@@ -212,3 +212,25 @@ def test_correspondence_forwards_its_own_cost_and_threshold():
     m = re.search(r"ekfslam_mex\('set_params',\s*tmp,[^\n]*\n", text)
     assert m and "h.s_cost" in m.group(0) and "h.s_thresh" in m.group(0)
     assert text.index("'set_params'") < text.index("'associate'")
+
+
+def test_landmark_selector_offers_the_synthetic_source():
+    """matlab/Landmark.m keeps the reference's surface (Landmark.m:12-33: Landmark(method), .landmarkObj, .method, getLandmark(laserdata, x))
+    and adds 'SYNTHETIC' -> SyntheticLandmarks, whose .landmark is the struct array of RANSAC.m:238-241 that measure() indexes
+    (EKF_SLAM.m:111,119).  Static checks only: MATLAB is not in the image; the Python twin (ekf_slam_amd/world.py::SyntheticLandmark)
+    is what runs, on the GPU, against the oracle's."""
+    methods, props, _ = _m_class("Landmark")
+    assert methods.get("Landmark") == 1 and methods.get("getLandmark") == 3 and {"landmarkObj", "method"} <= props
+    text = open(os.path.join(ROOT, "matlab", "Landmark.m")).read()
+    m = re.search(r"case\s+'SYNTHETIC'\s*\n\s*h\.landmarkObj\s*=\s*(\w+)\(\)", text)
+    assert m and m.group(1) == "SyntheticLandmarks"
+    assert re.search(r"case\s+'RANSAC'\s*\n\s*h\.landmarkObj\s*=\s*RANSAC\(\)", text)          # the reference's own source stays selectable
+    smethods, sprops, _ = _m_class("SyntheticLandmarks")
+    assert smethods.get("getLandmark") == 3 and smethods.get("plot") == 3 and "landmark" in sprops
+    stext = open(os.path.join(ROOT, "matlab", "SyntheticLandmarks.m")).read()
+    for field in ("loc", "observe", "index", "fresh"):                                           # RANSAC.m:238-241
+        assert re.search(r"h\.landmark\(at\)\.%s\s*=" % field, stext), field
+    assert "sortrows(observed_LL, 3)" in stext                                                   # rows in index order, as the Python twin returns them
+    # what measure() reads from the source exists on it: .landmarkObj.landmark with .index / .loc
+    e = open(os.path.join(ROOT, "matlab", "EKF_SLAM.m")).read()
+    assert "landmark_list.landmarkObj.landmark" in e and "landmark_list.getLandmark(laserData, h.x)" in e
