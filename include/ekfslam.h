@@ -94,8 +94,10 @@ typedef struct ekf_config {
                                        the device took come back as records that are checked against the prediction later: the
                                        next ekf_measure checks what has landed, every call that synchronises or reads or loads state
                                        (ekf_sync, ekf_get_*, ekf_set_*, ...) checks the rest first and returns EKF_ERR_STATE on a
-                                       mismatch (it cannot happen unless s was changed behind the library's back).  Unsharded
-                                       handles; a sharded handle decides as 0.
+                                       mismatch (it cannot happen unless s was changed behind the library's back).  On a sharded
+                                       handle the same loop runs on every shard (the association reads replicated data only): a
+                                       correction extracts the row-panel of the landmark the device names, exchanges it (the library's
+                                       communicator or the hook of transport (d)) and gathers on the exchanged panel.
                                     0: the decision is taken from the host mirror of s -- no association launch at all;
                                     1: the association kernel runs for every observation and the host WAITS for its decision;
                                     2: the kernel runs for every observation, the host dispatches on its mirror's decision (passed
@@ -168,8 +170,7 @@ int32_t ekf_associate(ekf_handle *h, const double z[3], const double R[4], int32
 /* On a sharded handle (cfg.world > 1) ekf_associate / ekf_measure need NO exchange, whatever w_pos: signatures, x, the robot block and
  * the strip are replicated, and so are the landmarks' own 2x2 diagonal blocks (live F64 copies that every correction's gather kernel
  * updates on every shard) -- every shard scores every landmark and takes the same decision, the unsharded handle's bit for bit.
- * (Until round 3 the diagonal blocks were only in the tiles, dealt over the shards, and a position cost needed ONE all-gather of the shards'
- * candidates.)  That exchange is still offered for hosts written around it: every shard scores the landmarks whose diagonal TILE it
+ * A second protocol exists for hosts that exchange candidates instead: every shard scores the landmarks whose diagonal TILE it
  * holds, the candidates {likelihood, index} -- and the position costs, if asked for -- travel in one all-gather of 4 (+ N) doubles per
  * shard run by the caller between _begin and _finish (ekf_exchange_info, ekf_exchange_local), and every shard takes the same strict
  * arg-min (lowest likelihood, lowest index on ties). */
