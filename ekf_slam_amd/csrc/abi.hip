@@ -107,6 +107,12 @@ struct ekf_handle {
     // work list of owned lower-triangle tiles for the active tile rows
     int2 *d_work = nullptr;
     int64_t nwork = 0, work_rows = -1, work_cap = 0;
+    // pinned staging of the work lists (refresh_work): uploads are queued on the stream with no host wait -- a stream
+    // synchronisation here drains a queue that may hold a whole batch and its pass (configs[4]: a 2.4 ms bubble per new tile row)
+    char *wl_stage = nullptr;
+    size_t wl_stage_bytes = 0;
+    hipEvent_t ev_wl = nullptr;
+    bool wl_busy = false;
     // the same tiles arranged as 8 per-XCD streams of super-tiles (batched flush: keeps each XCD's K/G working set
     // inside its own 4 MiB L2); stream x is work_xcd[x * xcd_len .. ), padded with (-1,-1)
     int2 *d_work_xcd = nullptr;
@@ -234,21 +240,29 @@ int32_t use_device(ekf_handle *h) {
     return EKF_OK;
 }
 
-// (re)build the list of owned tiles for the active tile rows
+// (re)build the list of owned tiles for the active tile rows.  The lists are built in pinned memory and uploaded by asynchronous
+// copies in stream order (the kernels that read them follow on the same stream); the staging area is reused only after the event
+// behind the previous upload has passed.
 int32_t refresh_work(ekf_handle *h) {
     const int64_t nt = ekf_tiles_for(n_mm(h), h->T);
     if (nt == h->work_rows) return EKF_OK;
-    std::vector<int2> w;
-    w.reserve((size_t)h->st.tm.slots_for_rows(nt));
+    const size_t b_work = (size_t)h->work_cap * sizeof(int2), b_xcd = 8 * b_work, b_segs = (size_t)h->segs_cap * sizeof(int4);
+    if (!h->wl_stage) {
+        h->wl_stage_bytes = b_work + b_xcd + b_segs;
+        HIPCHK(h, hipHostMalloc((void **)&h->wl_stage, h->wl_stage_bytes ? h->wl_stage_bytes : 16, hipHostMallocDefault));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_wl, hipEventDisableTiming));
+    }
+    if (h->wl_busy) { HIPCHK(h, hipEventSynchronize(h->ev_wl)); h->wl_busy = false; }
+    int2 *w = reinterpret_cast<int2 *>(h->wl_stage);
+    int2 *flat = reinterpret_cast<int2 *>(h->wl_stage + b_work);
+    int4 *segs = reinterpret_cast<int4 *>(h->wl_stage + b_work + b_xcd);
+    size_t nw = 0;
+    REQUIRE(h, h->st.tm.slots_for_rows(nt) <= h->work_cap, EKF_ERR_STATE, "work list overflow");
     for (int64_t I = 0; I < nt; ++I)
         for (int64_t J = 0; J <= I; ++J)
-            if (h->st.tm.mine(I, J)) w.push_back(make_int2((int)I, (int)J));
-    REQUIRE(h, (int64_t)w.size() <= h->work_cap, EKF_ERR_STATE, "work list overflow");
-    if (!w.empty()) {
-        HIPCHK(h, hipMemcpyAsync(h->d_work, w.data(), w.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));   // w is pageable and about to go out of scope
-    }
-    h->nwork = (int64_t)w.size();
+            if (h->st.tm.mine(I, J)) w[nw++] = make_int2((int)I, (int)J);
+    if (nw) HIPCHK(h, hipMemcpyAsync(h->d_work, w, nw * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    h->nwork = (int64_t)nw;
     h->work_rows = nt;
 
     // per-XCD streams: super-tiles of S x S tiles, largest first onto the least loaded stream
@@ -280,7 +294,7 @@ int32_t refresh_work(ekf_handle *h) {
         }
     } else {
         std::vector<int2> flat_order;
-        flat_order.reserve(w.size());
+        flat_order.reserve(nw);
         for (const Super &sp : supers) flat_order.insert(flat_order.end(), sp.tiles.begin(), sp.tiles.end());
         const size_t tot = flat_order.size();
         for (int x = 0; x < 8; ++x)
@@ -289,24 +303,23 @@ int32_t refresh_work(ekf_handle *h) {
     size_t len = 0;
     for (int x = 0; x < 8; ++x) len = std::max(len, stream[x].size());
     REQUIRE(h, (int64_t)(8 * len) <= 8 * h->work_cap, EKF_ERR_STATE, "XCD work list overflow");
-    std::vector<int2> flat(8 * len, make_int2(-1, -1));
-    for (int x = 0; x < 8; ++x) std::copy(stream[x].begin(), stream[x].end(), flat.begin() + x * len);
-    if (!flat.empty()) {
-        HIPCHK(h, hipMemcpyAsync(h->d_work_xcd, flat.data(), flat.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
+    std::fill(flat, flat + 8 * len, make_int2(-1, -1));
+    for (int x = 0; x < 8; ++x) std::copy(stream[x].begin(), stream[x].end(), flat + x * len);
+    if (len) HIPCHK(h, hipMemcpyAsync(h->d_work_xcd, flat, 8 * len * sizeof(int2), hipMemcpyHostToDevice, h->stream));
     h->xcd_len = (int64_t)len;
     if (h->d_segs) {                                  // the strip work list of the same tiles
         std::vector<int4> sg;
         const int64_t nsegs = build_strip_segments(h->st.tm, nt, sg);
         REQUIRE(h, (int64_t)sg.size() <= h->segs_cap, EKF_ERR_STATE, "strip work list overflow");
         if (!sg.empty()) {
-            HIPCHK(h, hipMemcpyAsync(h->d_segs, sg.data(), sg.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            std::copy(sg.begin(), sg.end(), segs);
+            HIPCHK(h, hipMemcpyAsync(h->d_segs, segs, sg.size() * sizeof(int4), hipMemcpyHostToDevice, h->stream));
         }
         h->aux.segs = h->d_segs;
         h->aux.nsegs = nsegs;
     }
+    HIPCHK(h, hipEventRecord(h->ev_wl, h->stream));
+    h->wl_busy = true;
     return EKF_OK;
 }
 
@@ -1284,6 +1297,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (h->h_parts) hipHostFree(h->h_parts);
     if (h->h_lrec) hipHostFree(h->h_lrec);
     if (h->h_small) hipHostFree(h->h_small);
+    if (h->wl_stage) { hipHostFree(h->wl_stage); hipEventDestroy(h->ev_wl); }
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return EKF_OK;

@@ -259,8 +259,7 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
         // a new row slab: its -K replaces this one's as soon as the last MFMA has been issued
         if (newk) load_k(nxt);
         // the item's result takes its tile's place in the registers; it leaves during the next item's first half
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mark(5);
+        mark(5);                                                           // (hipcc counts the wait for the tile pieces itself: vmcnt(8 + ...), the G pieces stay in flight)
         if (newk) mask_k();
 #pragma unroll
         for (int p = 0; p < 8; ++p)
