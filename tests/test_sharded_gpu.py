@@ -538,3 +538,55 @@ def test_prefetch_announced_before_the_pass_is_bit_identical(world, tile, batch,
     nb = (len(steps) + batch - 1) // batch
     assert results[0][2] == nb and results[1][2] == nb, (results[0][2], results[1][2], nb)
     one.close()
+
+
+def test_prefetch_next_statuses_and_withdrawal():
+    """ekf_prefetch_next: a no-op on an unsharded handle; refused (EKF_ERR_STATE) without a communicator or hook, with batch 1, with
+    the pass in F32 arithmetic; bad lists refused; an append before the batch completes drops the announcement -- results as without."""
+    import ctypes
+    from ekf_slam_amd import Engine, _lib as L
+    import bench
+    N, batch = 120, 4
+    w, x, s, d, U = bench.make_state(N, 20260131)
+    steps = bench.make_steps(w, N + 1, 3 * batch, [.01, 5.0])
+    plain = Engine(capacity=N + 2, tile=16, batch=batch)
+    plain.prefetch_next([1, 2])                                      # unsharded: nothing to exchange, nothing to refuse
+    raw = ctypes.create_string_buffer(L.EKF_COMM_ID_BYTES)
+    if L.lib().ekf_comm_unique_id(raw) != 0:
+        pytest.skip("librccl not loadable")
+    lone = Engine(force_sharded=1, capacity=N + 2, tile=16, batch=batch)
+    lone.load_lowrank_state(x, s, d, U)
+    with pytest.raises(L.EkfError) as ei:
+        lone.prefetch_next([1, 2])                                   # no communicator, no hook
+    assert ei.value.status == L.EKF_ERR_STATE
+    lone.comm_init(raw.raw)
+    with pytest.raises(L.EkfError) as ei:
+        lone.prefetch_next(list(range(batch + 1)))                   # more landmarks than a batch holds
+    assert ei.value.status == L.EKF_ERR_INVALID_ARG
+    with pytest.raises(L.EkfError) as ei:
+        lone.prefetch_next([N + 5])
+    assert ei.value.status == L.EKF_ERR_INDEX
+    b1 = Engine(force_sharded=1, capacity=N, tile=16, batch=1)
+    with pytest.raises(L.EkfError) as ei:
+        b1.prefetch_next([1])
+    assert ei.value.status == L.EKF_ERR_STATE
+    f32 = Engine(force_sharded=1, capacity=N, storage="f32_mixed", batch=batch)
+    with pytest.raises(L.EkfError) as ei:
+        f32.prefetch_next([1])
+    assert ei.value.status == L.EKF_ERR_STATE
+    # an append between the announcement and the batch's end: the announcement is dropped, the run equals the plain engine's
+    plain.load_lowrank_state(x, s, d, U)
+    R2 = np.diag([0.3, 4.0])
+    for eng in (plain, lone):
+        for t, (u, z, R, k) in enumerate(steps):
+            if t % batch == 0 and t + batch < len(steps):
+                eng.prefetch_next(sorted(set(kk for (_, _, _, kk) in steps[t + batch:t + 2 * batch] if kk < eng.N)))
+            eng.predict(u)
+            if t == 1:
+                eng.append(u, R2, [3.0, -2.0], float(N + 1))
+            eng.correct(z, R, min(k, eng.N - 1))
+        eng.flush()
+    np.testing.assert_array_equal(lone.get_x(), plain.get_x())
+    np.testing.assert_array_equal(lone.get_P(), plain.get_P())
+    for e in (plain, lone, b1, f32):
+        e.close()
