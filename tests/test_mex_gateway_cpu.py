@@ -234,3 +234,17 @@ def test_landmark_selector_offers_the_synthetic_source():
     # what measure() reads from the source exists on it: .landmarkObj.landmark with .index / .loc
     e = open(os.path.join(ROOT, "matlab", "EKF_SLAM.m")).read()
     assert "landmark_list.landmarkObj.landmark" in e and "landmark_list.getLandmark(laserData, h.x)" in e
+
+
+def test_synthetic_slam_facade_keeps_the_references_surface():
+    """matlab/SyntheticSLAM.m: SLAM.m's facade (SLAM.m:17-68,105-116) with the ROS subscribers replaced by a feed -- the members the
+    reference's drivers touch on a SLAM object exist with the reference's argument counts, and every member it calls on h.slam / h.LM
+    exists on matlab/EKF_SLAM.m / Landmark.m."""
+    methods, props, _ = _m_class("SyntheticSLAM")
+    assert {"LM", "slam", "algorithmName", "u"} <= props
+    assert methods.get("predict") == 2 and methods.get("measure") == 3 and methods.get("plot") == 1 and methods.get("runSlam") == 1
+    text = open(os.path.join(ROOT, "matlab", "SyntheticSLAM.m")).read()
+    assert "EKF_SLAM(varargin{:})" in text and "EKF_SLAM_UC(varargin{:})" in text and "Landmark(landmark_method)" in text
+    em, _, _ = _m_class("EKF_SLAM")
+    for member, nargs in re.findall(r"h\.slam\.(\w+)\(([^)]*)\)", text):
+        assert member in em and em[member] == 1 + len([a for a in nargs.split(",") if a.strip()]), member
