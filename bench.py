@@ -49,6 +49,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md chip table
 F32_MATRIX_PEAK = 157.3e12  # FLOP/s, dense v_mfma_f32_*_f32 (256 FLOPs/cycle/CU x 256 CUs x 2.4 GHz), same table
 F64_MATRIX_PEAK = 78.6e12   # FLOP/s, dense v_mfma_f64_*
+BF16_MATRIX_PEAK = 2.5e15   # FLOP/s, dense v_mfma_f32_*_bf16 (never the 2:1-sparsity figure), same table
 MIN_REGION_S = 0.2          # a timed region shorter than this is repeated (run_leg) and the median quoted
 MAX_REPEATS = 9
 

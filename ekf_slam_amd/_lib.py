@@ -16,7 +16,7 @@ EKF_ERR_INDEX, EKF_ERR_LOOKUP, EKF_ERR_STATE, EKF_ERR_COMM = 5, 6, 7, 8
 EKF_MODE_KNOWN, EKF_MODE_UC = 0, 1
 EKF_COMM_ID_BYTES = 128
 EKF_STORE_F64, EKF_STORE_F32 = 0, 1
-EKF_ARITH_F64, EKF_ARITH_F32 = 0, 1
+EKF_ARITH_F64, EKF_ARITH_F32, EKF_ARITH_SPLIT3 = 0, 1, 2
 (EKF_KERNEL_DOWNDATE, EKF_KERNEL_GATHER, EKF_KERNEL_PREDICT, EKF_KERNEL_ASSOCIATE, EKF_KERNEL_APPEND,
  EKF_KERNEL_ROWPANEL, EKF_KERNEL_EXCHANGE, EKF_KERNEL_COUNT) = range(8)
 

@@ -118,7 +118,7 @@ struct ekf_handle {
     int2 *d_work_xcd = nullptr;
     int64_t xcd_len = 0;
     // cfg.pass_arith = EKF_ARITH_F32: the strip form of the pass (flush32_pipe.h) -- its work list, the dump area
-    PassAux aux = { nullptr, 0, nullptr, 0 };
+    PassAux aux = { nullptr, 0, nullptr, 0, 0, nullptr, nullptr };
     int4 *d_segs = nullptr;
     int64_t segs_cap = 0;
     AssocDecision *d_partial = nullptr, *d_decision = nullptr, *h_decision = nullptr;
@@ -317,6 +317,7 @@ int32_t refresh_work(ekf_handle *h) {
         }
         h->aux.segs = h->d_segs;
         h->aux.nsegs = nsegs;
+        h->aux.cols = nt * h->T;
     }
     HIPCHK(h, hipEventRecord(h->ev_wl, h->stream));
     h->wl_busy = true;
@@ -1105,8 +1106,9 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     if (cfg->storage != EKF_STORE_F64 && cfg->storage != EKF_STORE_F32) return EKF_ERR_INVALID_ARG;
     if (cfg->mode != EKF_MODE_KNOWN && cfg->mode != EKF_MODE_UC) return EKF_ERR_INVALID_ARG;
     if (cfg->batch < 0 || cfg->batch > 64) return EKF_ERR_INVALID_ARG;
-    if (cfg->pass_arith != EKF_ARITH_F64 && !(cfg->pass_arith == EKF_ARITH_F32 && cfg->storage == EKF_STORE_F32 && T == 256))
-        return EKF_ERR_INVALID_ARG;                   // the f32-arithmetic pass exists for float tiles of edge 256 only
+    if (cfg->pass_arith != EKF_ARITH_F64 &&
+        !((cfg->pass_arith == EKF_ARITH_F32 || cfg->pass_arith == EKF_ARITH_SPLIT3) && cfg->storage == EKF_STORE_F32 && T == 256))
+        return EKF_ERR_INVALID_ARG;                   // the f32-arithmetic passes exist for float tiles of edge 256 only
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev)
         return EKF_ERR_NO_DEVICE;
@@ -1194,7 +1196,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
     HIPCHK(h, dalloc(h, &h->st.Gp, (size_t)(2 * ldm) * h->st.pcap * 2));
     h->st.Kp = h->st.Gp + (size_t)(2 * ldm) * h->st.pcap;
     h->st.Gp32 = nullptr; h->st.Kp32 = nullptr;
-    if (cfg->pass_arith == EKF_ARITH_F32) {
+    if (cfg->pass_arith != EKF_ARITH_F64) {
         HIPCHK(h, dalloc(h, &h->st.Gp32, (size_t)(2 * ldm) * h->st.pcap * 2));
         h->st.Kp32 = h->st.Gp32 + (size_t)(2 * ldm) * h->st.pcap;
         // the strip form of the pass: work list (every item once + one padded segment per 128-row slab and column range at most), dump
@@ -1209,6 +1211,11 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         float *dump = nullptr;
         HIPCHK(h, dalloc(h, &dump, (size_t)h->aux.grid * ekf_pipe32::kDumpFloats));
         h->aux.dump = dump;
+        if (cfg->pass_arith == EKF_ARITH_SPLIT3) {
+            // the bf16 planes of the pending pairs (flush32_split.h), cut from the float copies in front of every pass of 33-64 pairs
+            HIPCHK(h, dalloc(h, &h->aux.Kb3, pass_split_plane_elems(ldm)));
+            HIPCHK(h, dalloc(h, &h->aux.Gb3, pass_split_plane_elems(ldm)));
+        }
     }
     HIPCHK(h, dalloc(h, &h->st.small, 32));
     HIPCHK(h, dalloc(h, &h->d_work, (size_t)slots));

@@ -189,7 +189,11 @@ struct PassAux {
     int64_t nsegs;         // a multiple of 8
     float *dump;           // kDumpFloats floats per workgroup of the pass's grid
     int grid;              // workgroups the dump area was sized for (one per CU)
+    int64_t cols;          // rows / columns of the landmark block the active tile rows cover (a multiple of 256): what k_split_pairs cuts
+    uint16_t *Kb3, *Gb3;   // cfg.pass_arith = EKF_ARITH_SPLIT3 only (nullptr otherwise): the bf16 planes of the pending pairs, cut in front
+                           // of each pass (flush32_split.h: split_plane_elems(ldm) elements each)
 };
+size_t pass_split_plane_elems(int64_t ldm);     // uint16_t elements of PassAux::Kb3 (and of Gb3) for a landmark block of leading dimension ldm
 hipError_t launch_downdate(const DevState &st, void *dst, const int2 *work, int64_t nwork, const int2 *work_xcd, int64_t xcd_len,
                            int pstart, int npairs, int storage, int grid_cap, hipStream_t s, char *kname, const NextRow *nx = nullptr,
                            bool *extracted = nullptr, int arith = 0, const PassAux *aux = nullptr);

@@ -22,6 +22,7 @@
 #include "device_math.h"
 #include "flush32_mfma.h"     // kBlock, ring_slot, k_flush_mfma32
 #include "flush32_pipe.h"     // k_flush_strip32
+#include "flush32_split.h"    // k_split_pairs, k_flush_split3
 
 // The kernels, by family (each header is a fragment of THIS translation unit, not a stand-alone interface):
 namespace {
@@ -40,6 +41,7 @@ namespace {
 }  // namespace
 
 int gather_fuse_max_rows() { return kFuseMaxRows; }
+size_t pass_split_plane_elems(int64_t ldm) { return ekf_pipe32::split_plane_elems(ldm); }
 
 // ---------------------------------------------------------------------------------------------------
 // launch wrappers
@@ -227,6 +229,21 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if constexpr (sizeof(TS) == 4) {
             static const bool use_strip = ekf_tune_int("EKF_PASS_STRIP", 1) != 0;
+            if (arith == 2 && npairs > 32 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0 && aux->Kb3 && aux->Gb3) {
+                // cfg.pass_arith = EKF_ARITH_SPLIT3, 33-64 pairs: the float copies cut into three bf16 planes (logical pair order, zeros beyond
+                // npairs), then the strip form of the pass on the bf16 matrix pipe (flush32_split.h) -- bound by HBM, not by the matrix pipe
+                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_split3<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   ekf_pipe32::lds_bytes_split());
+                if (attr == hipSuccess) {
+                    hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(aux->cols / 256), ekf_pipe32::kKB, 2), dim3(256), 0, s, (const float *)st.Kp32,
+                                       (const float *)st.Gp32, aux->Kb3, aux->Gb3, st.pair_stride, st.ldm, aux->cols, pstart, st.pcap, npairs);
+                    hipLaunchKernelGGL((ekf_pipe32::k_flush_split3<2>), dim3((unsigned)aux->grid), dim3(512), ekf_pipe32::lds_bytes_split(), s,
+                                       (const float *)st.tiles, (float *)dstv, aux->segs, aux->nsegs, (const uint16_t *)aux->Kb3, (const uint16_t *)aux->Gb3, st.ldm,
+                                       st.tm, aux->dump);
+                    if (kname) snprintf(kname, 64, "k_flush_split3<2>");
+                    return true;
+                }
+            }
             if (use_strip && arith == 1 && npairs > 56 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0) {
                 // 57-64 pairs (eight stages of eight): the strip form -- one persistent workgroup per CU walks row strips with -K in its
                 // wavefronts' registers and a whole item's G double-buffered in LDS (flush32_pipe.h): 7.3 ms against 8.1-8.3 at 40 000
@@ -241,7 +258,7 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                     return true;
                 }
             }
-            if (arith == 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32: the f32 matrix pipe (one or two pairs: the pass is
+            if (arith >= 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32 (and EKF_ARITH_SPLIT3 up to 32 pairs): the f32 matrix pipe (one or two pairs: the pass is
                                                                       // purely HBM-bound and the F64-arithmetic kernel below streams it 5 % faster, 4.0 against 4.3 ms at 40 k)
 #define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
                                   hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \

@@ -32,11 +32,12 @@ class Engine:
         self._check(self.lib.ekf_config_default(ctypes.byref(cfg), m), None)
         cfg.capacity_landmarks = int(capacity)
         cfg.tile = int(tile)
-        if storage not in ("f64", "f32", "f32_mixed"):
-            raise TypeError("Engine: storage is 'f64', 'f32' (float tiles, F64 arithmetic) or 'f32_mixed' (float tiles, the pass over P "
-                            "in F32 arithmetic on the matrix pipe: cfg.pass_arith = EKF_ARITH_F32)")
+        if storage not in ("f64", "f32", "f32_mixed", "f32_split"):
+            raise TypeError("Engine: storage is 'f64', 'f32' (float tiles, F64 arithmetic), 'f32_mixed' (float tiles, the pass over P "
+                            "in F32 arithmetic on the matrix pipe: cfg.pass_arith = EKF_ARITH_F32) or 'f32_split' (the same with every "
+                            "float operand cut into three bfloat16 pieces, on the bf16 matrix pipe: EKF_ARITH_SPLIT3)")
         cfg.storage = L.EKF_STORE_F64 if storage == "f64" else L.EKF_STORE_F32
-        cfg.pass_arith = L.EKF_ARITH_F32 if storage == "f32_mixed" else L.EKF_ARITH_F64
+        cfg.pass_arith = {"f32_mixed": L.EKF_ARITH_F32, "f32_split": L.EKF_ARITH_SPLIT3}.get(storage, L.EKF_ARITH_F64)
         cfg.device, cfg.rank, cfg.world, cfg.batch = int(device), int(rank), int(world), int(batch)
         cfg.async_flush = 1 if async_flush else 0
         if device_assoc is not None:              # None: the mode's default (uc: 3, the device-resident loop); include/ekfslam.h

@@ -46,7 +46,8 @@ enum { EKF_MODE_KNOWN = 0,   /* EKF_SLAM.m    : known correspondence   */
 enum { EKF_STORE_F64 = 0,    /* P tiles stored as double                               */
        EKF_STORE_F32 = 1 };  /* P tiles stored as float, every solve still in double   */
 enum { EKF_ARITH_F64 = 0,    /* the pass over P forms P - sum K_i G_i in double (one rounding per pass when the tiles are float) */
-       EKF_ARITH_F32 = 1 };  /* F32 tiles with tile = 256 only: the pass runs on the f32 matrix pipe (cfg.pass_arith below)      */
+       EKF_ARITH_F32 = 1,    /* F32 tiles with tile = 256 only: the pass runs on the f32 matrix pipe (cfg.pass_arith below)      */
+       EKF_ARITH_SPLIT3 = 2 };/* as EKF_ARITH_F32, every float operand cut exactly into three bfloat16 pieces: bf16 matrix pipe  */
 
 /* Hard-coded property defaults of the reference collected in one struct
  * (EKF_SLAM.m:12-16, EKF_SLAM_UC.m:13,16). */
@@ -118,7 +119,15 @@ typedef struct ekf_config {
                                     EKF_ARITH_F64.  Passes of one or two pairs are purely HBM-bound and keep the F64-arithmetic kernel.
                                     The innovation, S, K, x, the robot block, the strip and the landmarks' 2x2 diagonal blocks are F64 as
                                     always.  Costs pcap x 4 N floats for the copies.  Measured against the F64 engine: DESIGN.md section 5
-                                    (the whole configs[4] workload, 40 000 -> 50 000 landmarks: 2e-8). */
+                                    (the whole configs[4] workload, 40 000 -> 50 000 landmarks: 2e-8).
+                                    EKF_ARITH_SPLIT3 (same preconditions): the same float copies, each cut EXACTLY into three bfloat16
+                                    pieces (3 x 8 significant bits) in front of the pass; a product is the sum of the six partial
+                                    products that matter (what is dropped is below 2^-26 of it -- a quarter of one float rounding),
+                                    each exact in float, summed in float on the bf16 matrix pipe from zero, then added to the tile
+                                    value once.  Same error class as EKF_ARITH_F32 (a float sum of 2m terms; measured against an F64
+                                    sum beside the fmaf chain: DESIGN.md section 5), NOT the same bits; at 33-64 pending pairs the
+                                    pass is then bound by HBM instead of the f32 matrix pipe.  Up to 32 pairs: EKF_ARITH_F32's kernels.
+                                    Costs 2 x 768 bytes per row of P for the planes. */
     int32_t reserved[2];
 } ekf_config;
 

@@ -4,7 +4,7 @@
 Starts from N0 bulk-loaded landmarks (P = D + U U'), capacity N0 + steps; every step = predict + append of one new
 landmark + one correction on a cycling landmark (EKF_SLAM.m:40-51, :67-98, :124-145).  Prints one JSON line.
 
-    python scripts/bench_config5.py [--landmarks 40000] [--steps 512] [--batch 12] [--storage f32|f32_mixed|f64]
+    python scripts/bench_config5.py [--landmarks 40000] [--steps 512] [--batch 12] [--storage f32|f32_mixed|f32_split|f64]
 """
 import argparse
 import json
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=12, help="12 is the usable point of the F64-arithmetic pass on float tiles; 32-64 with --storage f32_mixed")
-    ap.add_argument("--storage", default="f32", help="f32: float tiles, F64 arithmetic; f32_mixed: float tiles, the pass in F32 arithmetic (cfg.pass_arith); f64")
+    ap.add_argument("--storage", default="f32", help="f32: float tiles, F64 arithmetic; f32_mixed: float tiles, the pass in F32 arithmetic (cfg.pass_arith); f32_split: the same in split arithmetic (every float operand cut into three bfloat16 pieces, bf16 matrix pipe); f64")
     args = ap.parse_args()
     from ekf_slam_amd import Engine, _lib as L
     from ekf_slam_amd.world import World
@@ -115,21 +115,26 @@ def main():
     pairs_avg = args.steps / max(launches, 1)
     flops = 4.0 * pairs_avg * n_mid * (n_mid + 1) / 2
     f32_pass = args.storage == "f32_mixed"
-    pipe_peak = bench.F32_MATRIX_PEAK if f32_pass else bench.F64_MATRIX_PEAK
+    split_pass = args.storage == "f32_split"
+    # split arithmetic: six bf16 partial products per product -- the matrix pipe EXECUTES 6 x the algorithmic flops, priced against the dense
+    # bf16 peak; `algorithmic_flops_per_launch` stays the algorithmic figure
+    exec_factor = 6.0 if split_pass else 1.0
+    pipe_peak = bench.BF16_MATRIX_PEAK if split_pass else bench.F32_MATRIX_PEAK if f32_pass else bench.F64_MATRIX_PEAK
     hbm_frac = b_alg / (avg_ms * 1e-3) / bench.HBM_PEAK
-    pipe_frac = flops / (avg_ms * 1e-3) / pipe_peak
+    pipe_frac = exec_factor * flops / (avg_ms * 1e-3) / pipe_peak
     bound = "mfma" if pipe_frac > hbm_frac else "hbm"
     pmc = load_pmc(N0, args.batch, args.storage)
     if pmc is not None and pmc.get("kernel") and pmc["kernel"].split("<")[0] != kernel_full.split("<")[0]:
         pmc = None                                            # measured on another kernel: does not describe these launches
     roof = {"bound": bound,
-            "achieved": flops / (avg_ms * 1e-3) / 1e12 if bound == "mfma" else b_alg / (avg_ms * 1e-3) / 1e9,
+            "achieved": exec_factor * flops / (avg_ms * 1e-3) / 1e12 if bound == "mfma" else b_alg / (avg_ms * 1e-3) / 1e9,
             "peak": pipe_peak / 1e12 if bound == "mfma" else bench.HBM_PEAK / 1e9,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": pipe_frac if bound == "mfma" else hbm_frac,
             "roofs": {"hbm": {"achieved": b_alg / (avg_ms * 1e-3) / 1e9, "peak": bench.HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac},
-                      "mfma": {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak / 1e12, "unit": "TFLOP/s", "frac": pipe_frac,
-                               "pipe": "v_mfma_f32_16x16x4_f32" if f32_pass else "v_mfma_f64_16x16x4_f64"}},
+                      "mfma": {"achieved": exec_factor * flops / (avg_ms * 1e-3) / 1e12, "peak": pipe_peak / 1e12, "unit": "TFLOP/s", "frac": pipe_frac,
+                               "executed_over_algorithmic_flops": exec_factor,
+                               "pipe": "v_mfma_f32_16x16x32_bf16" if split_pass else "v_mfma_f32_16x16x4_f32" if f32_pass else "v_mfma_f64_16x16x4_f64"}},
             # HBM bytes per FULL-batch launch from PMC counters (their own rocprofv3 passes): from the committed summary of this
             # launch shape, null when none matches
             "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "from_committed_profile": pmc,
@@ -138,7 +143,7 @@ def main():
             "algorithmic_flops_per_launch": flops, "update_steps_per_launch": pairs_avg}
     out = {"metric": "EKF update-steps/sec at N landmarks; HBM GB/s on (I\u2212KH)P vs roofline",
            "value": args.steps / dt, "unit": "update-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s" % {"f32": "f32 tiles, f64 pass arithmetic", "f32_mixed": "f32 tiles, f32 pass arithmetic (matrix pipe)", "f64": "f64 tiles"}[args.storage], "data": "synthetic",
+           "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s" % {"f32": "f32 tiles, f64 pass arithmetic", "f32_mixed": "f32 tiles, f32 pass arithmetic (matrix pipe)", "f32_split": "f32 tiles, f32-equivalent split pass arithmetic (3 x bf16 pieces per operand, six exact partial products, f32 accumulation: bf16 matrix pipe)", "f64": "f64 tiles"}[args.storage], "data": "synthetic",
            "config": {"workload": "configs[4] shape on 1 GPU: %d -> %d landmarks, %s tile storage, F64 solve, step = predict + "
                                   "append + 1 correction (streaming landmark append)" % (N0 + args.warmup, e_N[0], args.storage),
                       "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,

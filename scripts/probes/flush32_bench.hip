@@ -13,11 +13,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "flush32_mfma.h"
 #include "flush32_pipe.h"
+#include "flush32_split.h"
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -62,6 +64,30 @@ __global__ void k_diff(const float *a, const float *b, int64_t n, unsigned long 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         if (__float_as_uint(a[i]) != __float_as_uint(b[i])) { ++mine; atomicMin(first, (unsigned long long)i); }
     if (mine) atomicAdd(bad, mine);
+}
+
+// ACC=1: the error of a pass's UPDATE against an F64 sum, entry by entry: err = |out - (tile + sum64)|, S = sum |k||g|; max and mean of err / S
+// (with zero tiles, ZERO_TILES=1, `out` IS the float sum and err its accumulation error alone)
+__global__ void k_acc(const float *tiles, const float *out, const int2 *work, const float *Kil, const float *Gil, int64_t pair_stride, int pstart, int pcap,
+                      int npairs, TileMap tm, unsigned long long *maxbits, double *sum, unsigned long long *cnt) {
+    constexpr int T = 256;
+    const int2 ij = work[blockIdx.x / (T * T / 256)];
+    const int r = blockIdx.x % (T * T / 256), c = threadIdx.x;
+    const int64_t off = tm.tile_offset(ij.x, ij.y) + (int64_t)r * T + c;
+    double acc = 0.0, S = 0.0;
+    for (int p = 0; p < npairs; ++p) {
+        const int64_t so = (int64_t)ring_slot(pstart, p, pcap) * pair_stride;
+        const double kx = Kil[so + 2 * ((int64_t)ij.x * T + r)], ky = Kil[so + 2 * ((int64_t)ij.x * T + r) + 1];
+        const double gx = Gil[so + 2 * ((int64_t)ij.y * T + c)], gy = Gil[so + 2 * ((int64_t)ij.y * T + c) + 1];
+        acc += -kx * gx; acc += -ky * gy;
+        S += fabs(kx * gx) + fabs(ky * gy);
+    }
+    const double err = fabs((double)out[off] - ((double)tiles[off] + acc)) / (S > 0 ? S : 1.0);
+    atomicMax(maxbits, (unsigned long long)__double_as_longlong(err));
+    // (one atomic per wavefront would do; this is a probe)
+    double e = err;
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sum, e); atomicAdd(cnt, 64ull); }
 }
 
 // PREWARM_US: a register-only MFMA loop on every CU for about that long, launched right in front of each timed launch after the idle gap
@@ -153,7 +179,7 @@ int main(int argc, char **argv) {
     CHK(hipMalloc(&tiles, telems * 4));
     CHK(hipMalloc(&Kil, pair_stride * pcap * 4)); CHK(hipMalloc(&Gil, pair_stride * pcap * 4));
     CHK(hipMalloc(&Kn, pair_stride * pcap * 4)); CHK(hipMalloc(&Gpl, pair_stride * pcap * 4));
-    k_fill<<<2048, 256>>>(tiles, telems, 1u, 10.0f);
+    k_fill<<<2048, 256>>>(tiles, telems, 1u, (getenv("ZERO_TILES") && atoi(getenv("ZERO_TILES"))) ? 0.0f : 10.0f);
     k_fill<<<1024, 256>>>(Kil, pair_stride * pcap, 2u, 0.05f);
     k_fill<<<1024, 256>>>(Gil, pair_stride * pcap, 3u, 0.05f);
     k_planar<<<1024, 256>>>(Kil, Kn, ldm, pair_stride, pcap, -1.0f);
@@ -177,6 +203,30 @@ int main(int argc, char **argv) {
     auto launch_strip = [&](float *dstp, int v) {
         hipLaunchKernelGGL(vs[v].fn, dim3(grid), dim3(vs[v].threads), vs[v].lds, 0, (const float *)tiles, dstp, d_segs, nsegs, (const float *)Kn,
                            (const float *)Gpl, pair_stride, ldm, pstart, pcap, npairs, tm, dump, (unsigned long long *)nullptr);
+    };
+
+    // split arithmetic (flush32_split.h): the operand planes are cut from the planar float copies in front of every pass
+    uint16_t *Kb3, *Gb3;
+    CHK(hipMalloc(&Kb3, ekf_pipe32::split_plane_elems(ldm) * 2)); CHK(hipMalloc(&Gb3, ekf_pipe32::split_plane_elems(ldm) * 2));
+    CHK(hipMemset(Kb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2)); CHK(hipMemset(Gb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2));
+    typedef void (*fsp_t)(const float *, float *, const int4 *, int64_t, const uint16_t *, const uint16_t *, int64_t, TileMap, float *);
+    // ABL=1: the ablations beside the kernel (diagnostic instances: results are wrong by construction)
+    struct VarP { const char *name; fsp_t fn; };
+    const VarP vp[] = {
+        { "k_flush_split3<2>", ekf_pipe32::k_flush_split3<2, 0> },
+        { "  abl: no tile stores", ekf_pipe32::k_flush_split3<2, 1> },
+        { "  abl: no tile loads", ekf_pipe32::k_flush_split3<2, 2> },
+        { "  abl: no tile traffic", ekf_pipe32::k_flush_split3<2, 3> },
+        { "  abl: no G loads", ekf_pipe32::k_flush_split3<2, 4> },
+        { "  abl: no traffic at all", ekf_pipe32::k_flush_split3<2, 7> },
+    };
+    const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 1;
+    for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split()));
+    auto launch_split = [&](float *dstp, bool cut, int v = 0) {
+        if (cut) hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(ldm / 256), ekf_pipe32::kKB, 2), dim3(256), 0, 0, (const float *)Kn, (const float *)Gpl, Kb3, Gb3,
+                                    pair_stride, ldm, ldm, pstart, pcap, npairs);
+        hipLaunchKernelGGL(vp[v].fn, dim3(grid), dim3(512), ekf_pipe32::lds_bytes_split(), 0, (const float *)tiles, dstp, d_segs, nsegs,
+                           (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
     };
     auto strip_ok = [&](int v) { return (npairs + 7) / 8 == 8; };      // (instantiated for eight stages: 57-64 pairs)
     if (getenv("STAMP") && atoi(getenv("STAMP")) == 2) {
@@ -209,6 +259,26 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+
+    if (getenv("ACC") && atoi(getenv("ACC"))) {
+        float *o; CHK(hipMalloc(&o, telems * 4));
+        unsigned long long *d_m; double *d_s;
+        CHK(hipMalloc(&d_m, 24)); d_s = (double *)(d_m + 1);
+        auto report = [&](const char *name) {
+            CHK(hipMemset(d_m, 0, 24));
+            k_acc<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, Kil, Gil, pair_stride, pstart, pcap, npairs, tm, d_m, d_s, d_m + 2);
+            CHK(hipDeviceSynchronize());
+            unsigned long long h[3]; CHK(hipMemcpy(h, d_m, 24, hipMemcpyDeviceToHost));
+            double mx, sm; memcpy(&mx, &h[0], 8); memcpy(&sm, &h[1], 8);
+            printf("accuracy %-30s pairs %d: err / sum|k g|  max %.3e (%.2f x 2^-24)  mean %.3e (%.3f x 2^-24)\n", name, npairs, mx, mx * 16777216.0, sm / (double)h[2], sm / (double)h[2] * 16777216.0);
+        };
+        CHK(hipMemset(o, 0xee, telems * 4));
+        k_ref<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, (int64_t)tot, Kil, Gil, pair_stride, pstart, pcap, npairs, tm);
+        CHK(hipDeviceSynchronize()); report("fmaf chain (reference)");
+        CHK(hipMemset(o, 0xee, telems * 4)); launch_old(o); CHK(hipDeviceSynchronize()); report("k_flush_mfma32");
+        if (npairs > 32) { CHK(hipMemset(o, 0xee, telems * 4)); launch_split(o, true); CHK(hipDeviceSynchronize()); report("k_flush_split3<2>"); }
+        CHK(hipFree(o));
+    }
     int rc = 0;
     if (check) {
         CHK(hipMalloc(&out_a, telems * 4)); CHK(hipMalloc(&out_b, telems * 4));
@@ -236,11 +306,14 @@ int main(int argc, char **argv) {
         CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
         std::vector<std::string> names = { "k_flush_mfma32<256,4,2,3,early>" };
         for (int v = 0; v < nvs; ++v) names.push_back(vs[v].name);
+        names.push_back("k_split_pairs + k_flush_split3<2>");
+        for (int v = 0; v < nvp; ++v) names.push_back(std::string(vp[v].name) + (v ? "" : " alone"));
         const int nk = (int)names.size();
         std::vector<std::vector<float>> ms(nk);
         for (int r = 0; r < rounds + 1; ++r)
             for (int k = 0; k < nk; ++k) {
-                if (k >= 1 && !strip_ok(k - 1)) continue;
+                if (k >= 1 && k <= nvs && !strip_ok(k - 1)) continue;
+                if (k > nvs && npairs <= 32) continue;
                 const int gap_ms = getenv("GAP_MS") ? atoi(getenv("GAP_MS")) : 0;      // GAP_MS: an idle device between single timed launches (the engine's duty cycle)
                 if (gap_ms > 0) {
                     for (int rep = 0; rep < 3; ++rep) {
@@ -248,7 +321,7 @@ int main(int argc, char **argv) {
                         if (getenv("PREWARM_US")) hipLaunchKernelGGL(k_prewarm, dim3(grid * 2), dim3(256), 0, 0, dump, (long long)atoi(getenv("PREWARM_US")) * 2100);      // (readcyclecounter: shader cycles, ~2.1 GHz)
                         if (getenv("PREWARM_MB")) hipLaunchKernelGGL(k_prewarm_mem, dim3(2048), dim3(256), 0, 0, (const float4 *)tiles, (long long)atoi(getenv("PREWARM_MB")) * 65536ll, dump);
                         CHK(hipEventRecord(e0, 0));
-                        if (k == 0) launch_old(tiles); else launch_strip(tiles, k - 1);
+                        if (k == 0) launch_old(tiles); else if (k <= nvs) launch_strip(tiles, k - 1); else launch_split(tiles, k == nvs + 1, k > nvs + 1 ? k - nvs - 2 : 0);
                         tm.reverse ^= (reverse == 2);
                         CHK(hipEventRecord(e1, 0));
                         CHK(hipEventSynchronize(e1));
@@ -259,7 +332,7 @@ int main(int argc, char **argv) {
                 }
                 CHK(hipEventRecord(e0, 0));
                 for (int rep = 0; rep < 3; ++rep) {
-                    if (k == 0) launch_old(tiles); else launch_strip(tiles, k - 1);
+                    if (k == 0) launch_old(tiles); else if (k <= nvs) launch_strip(tiles, k - 1); else launch_split(tiles, k == nvs + 1, k > nvs + 1 ? k - nvs - 2 : 0);
                     tm.reverse ^= (reverse == 2);
                 }
                 CHK(hipEventRecord(e1, 0));
