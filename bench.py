@@ -166,13 +166,17 @@ def other_configs(timeout_s=300):
     """BASELINE.json's other single-GPU configurations, measured in the same invocation (each in a fresh child process, after the headline
     legs; a failure there is reported in its own entry and never touches the headline): configs[1] -- 1 000 landmarks, unknown
     correspondence, the device-resident measure loop (scripts/bench_config2.py) -- and configs[4]'s whole workload on ONE GPU -- 40 000
-    landmarks bulk-loaded, predict + append + correction per step until 50 000, float tiles, the pass in F32 arithmetic at batch 64
-    (scripts/bench_config5.py).  Parity of both is the test suite's business (tests/test_config2_uc_gpu.py, tests/test_full_size_gpu.py)."""
+    landmarks bulk-loaded, predict + append + correction per step until 50 000, float tiles, the pass in F32 arithmetic at batch 64 and
+    again in split arithmetic (scripts/bench_config5.py).  Parity of both is the test suite's business (tests/test_config2_uc_gpu.py, tests/test_full_size_gpu.py)."""
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     runs = (("configs[1]", ["scripts/bench_config2.py", "--batch", "8"]),
             ("configs[4] on one GPU", ["scripts/bench_config5.py", "--storage", "f32_mixed", "--batch", "64", "--landmarks", "40000",
-                                       "--steps", "9936", "--warmup", "64"]))
+                                       "--steps", "9936", "--warmup", "64"]),
+            # the same workload with the pass in split arithmetic (cfg.pass_arith = EKF_ARITH_SPLIT3: three bf16 pieces per float operand,
+            # six exact partial products, float accumulation -- the fmaf chain's error class, not its bits; flush32_split.h)
+            ("configs[4] on one GPU, split arithmetic", ["scripts/bench_config5.py", "--storage", "f32_split", "--batch", "64", "--landmarks", "40000",
+                                                         "--steps", "9936", "--warmup", "64"]))
     out = {}
     for key, cmd in runs:
         try:

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 
 // One work-list entry = a 128 x 128 item (flush32_pipe.h: strip_entry, the segments of build_strip_segments); an item = kNCH chunks of two
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
-// kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads -- never the product kernel
+// kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
+// tile stores / loads, 32 the tile pieces two per group in the item's first quarter -- never the product kernel
 template <int kNCH = 2, int kAbl = 0>
 __global__ __launch_bounds__(512)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
@@ -169,8 +170,16 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         return reinterpret_cast<const char *>(Gb) + ((((int64_t)p * kKB + 2 * ch + kbl) * ncg + cg) * 4 + e) * 1024 + lane * 16;
     };
     auto load_g = [&](const StripItem &q, int ch, int j) { if (!(kAbl & 4)) gq[j] = *reinterpret_cast<const u4_t *>(g_src(q, ch, j)); };
-    auto write_g = [&](int buf, int j) {
-        *reinterpret_cast<u4_t *>(smem + (uint32_t)buf * kSplitChunk + (uint32_t)(wave + 8 * j) * 1024 + (uint32_t)lane * 16) = gq[j];
+    // Items of odd checkerboard parity compute the update with the OPPOSITE sign (G's sign bits flipped on the way into LDS: exact) and subtract
+    // it.  v_mfma_f32_16x16x32_bf16 aligns its 32 products to the largest and cuts the smaller ones off below 2^-24 of it TOWARDS MINUS
+    // INFINITY (scripts/probes/mfma_bf16_round.hip), then adds C with round-to-nearest: every entry's sum carries a small bias of one sign
+    // (-0.014 float ulps of sum |k g| against the mean error's 0.2) -- invisible per entry, coherent over the 10^10 entries of P and over the
+    // passes (the sum-of-entries digest drifted 6e-8 over configs[4]'s 156 passes).  With the sign alternating from item to item the bias
+    // alternates too.  Per entry nothing changes: the same products, the same rounding, mirrored.
+    auto parity = [&](const StripItem &q) { return (uint32_t)(((q.krow0 ^ q.gcol0) >> 7) & 1); };
+    auto write_g = [&](int buf, int j, uint32_t flip) {
+        const uint32_t fm = flip ? 0x80008000u : 0u;
+        *reinterpret_cast<u4_t *>(smem + (uint32_t)buf * kSplitChunk + (uint32_t)(wave + 8 * j) * 1024 + (uint32_t)lane * 16) = gq[j] ^ u4_t{ fm, fm, fm, fm };
     };
     // Tile traffic as in k_flush_strip32: ONE register buffer of eight 16-byte pieces carries two items at a time -- in the item's first
     // chunk each piece's register first gives up the PREVIOUS item's finished entries (a store), then takes the CURRENT item's tile value (a
@@ -206,7 +215,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     for (int j = 0; j < 6; ++j) load_g(cur, 0, j);
     load_k(cur);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { write_g(0, j); if (kNCH == 2) load_g(cur, 1, j); else load_g(nxt, 0, j); }
+    for (int j = 0; j < 6; ++j) { write_g(0, j, parity(cur)); if (kNCH == 2) load_g(cur, 1, j); else load_g(nxt, 0, j); }
     zero_acc();
     __shared__ int arrived;
     if (tid == 0) __hip_atomic_store(&arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -228,14 +237,14 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (gl == 0) {
-                // The next chunk's G into the buffer the last WAIT freed, the chunk after it on its way: ALL SIX pieces here, in front of the chunk's
-                // tile traffic.  Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load AND
-                // store; with the G pieces spread over the chunk between the tile pieces (k_flush_strip32's order) each of these waits forced
-                // the tile stores and loads issued one chunk earlier to have completed -- 5.17 ms at 40 000 landmarks, 3.2 without the stores
-                // (ablations, round4_tuning.md 53).  Here the G pieces waited for are older than every tile piece in flight.
+                // The next chunk's G into the buffer the last WAIT freed, the chunk after it on its way: all six pieces here, in front of the chunk's
+                // tile traffic.  (Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load and store;
+                // here the G pieces waited for are older than every tile piece in flight.  Spread over the chunk between the tile pieces --
+                // k_flush_strip32's order -- the pass measured the same, 5.18 ms at 40 000 landmarks: round4_tuning.md 53.)
+                const uint32_t flip_next = (kNCH == 2 && ch == 0) ? parity(cur) : parity(nxt);      // whose G these pieces are
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    write_g(buf ^ 1, j);
+                    write_g(buf ^ 1, j, flip_next);
                     __builtin_amdgcn_sched_barrier(0);                     // (hipcc otherwise hoists the six loads over the writes, into six more registers each: spills)
                     if (kNCH == 2) { if (ch == 0) load_g(nxt, 0, j); else load_g(nxt, 1, j); }
                     else load_g(nn, 0, j);
@@ -243,10 +252,15 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 }
             }
             mfma_group(2 * ch + (gl >> 2), gl & 3, fb[gi & 1]);
-            if (gi < 8) {
+            if ((kAbl & 32) ? gi < 4 : gi < 8) {
                 // the tile pieces: the register first gives up the PREVIOUS item's finished entries, then takes this item's tile value
-                if (!(kAbl & 1)) __builtin_nontemporal_store(tl[gi], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(gi)));
-                if (!(kAbl & 2)) tl[gi] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(gi)));
+#pragma unroll
+                for (int p = (kAbl & 32) ? 2 * gi : gi; p < ((kAbl & 32) ? 2 * gi + 2 : gi + 1); ++p) {
+                    f4_t *po = reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p));
+                    const f4_t *pi = reinterpret_cast<const f4_t *>(in_base + piece_off(p));
+                    if (!(kAbl & 1)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
+                    if (!(kAbl & 2)) { if (kAbl & 16) tl[p] = *pi; else tl[p] = __builtin_nontemporal_load(pi); }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (gl == 7 && gi + 1 < NG) {
@@ -258,10 +272,11 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             }
         }
         if (newk) load_k(nxt);
+        const float sgn = parity(cur) ? -1.0f : 1.0f;
 #pragma unroll
         for (int p = 0; p < 8; ++p)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) tl[p][e] += acc[p >> 2][e][p & 3];
+            for (int e = 0; e < 4; ++e) tl[p][e] = fmaf(acc[p >> 2][e][p & 3], sgn, tl[p][e]);     // (exact product: one rounding, as tl + acc)
         zero_acc();
         out_base = reinterpret_cast<const char *>(dst + cur.toff);
         if (nxt.krow0 < 0) break;

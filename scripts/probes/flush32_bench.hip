@@ -69,7 +69,7 @@ __global__ void k_diff(const float *a, const float *b, int64_t n, unsigned long 
 // ACC=1: the error of a pass's UPDATE against an F64 sum, entry by entry: err = |out - (tile + sum64)|, S = sum |k||g|; max and mean of err / S
 // (with zero tiles, ZERO_TILES=1, `out` IS the float sum and err its accumulation error alone)
 __global__ void k_acc(const float *tiles, const float *out, const int2 *work, const float *Kil, const float *Gil, int64_t pair_stride, int pstart, int pcap,
-                      int npairs, TileMap tm, unsigned long long *maxbits, double *sum, unsigned long long *cnt) {
+                      int npairs, TileMap tm, unsigned long long *maxbits, double *sum, unsigned long long *cnt, double *ssum) {
     constexpr int T = 256;
     const int2 ij = work[blockIdx.x / (T * T / 256)];
     const int r = blockIdx.x % (T * T / 256), c = threadIdx.x;
@@ -85,9 +85,9 @@ __global__ void k_acc(const float *tiles, const float *out, const int2 *work, co
     const double err = fabs((double)out[off] - ((double)tiles[off] + acc)) / (S > 0 ? S : 1.0);
     atomicMax(maxbits, (unsigned long long)__double_as_longlong(err));
     // (one atomic per wavefront would do; this is a probe)
-    double e = err;
-    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(sum, e); atomicAdd(cnt, 64ull); }
+    double e = err, sg = ((double)out[off] - ((double)tiles[off] + acc)) / (S > 0 ? S : 1.0);
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_down(e, o); sg += __shfl_down(sg, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(sum, e); atomicAdd(cnt, 64ull); atomicAdd(ssum, sg); }
 }
 
 // PREWARM_US: a register-only MFMA loop on every CU for about that long, launched right in front of each timed launch after the idle gap
@@ -219,6 +219,10 @@ int main(int argc, char **argv) {
         { "  abl: no tile traffic", ekf_pipe32::k_flush_split3<2, 3> },
         { "  abl: no G loads", ekf_pipe32::k_flush_split3<2, 4> },
         { "  abl: no traffic at all", ekf_pipe32::k_flush_split3<2, 7> },
+        { "  var: plain tile stores", ekf_pipe32::k_flush_split3<2, 8> },
+        { "  var: plain tile loads", ekf_pipe32::k_flush_split3<2, 16> },
+        { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> },
+        { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> },
     };
     const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 1;
     for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split()));
@@ -263,14 +267,14 @@ int main(int argc, char **argv) {
     if (getenv("ACC") && atoi(getenv("ACC"))) {
         float *o; CHK(hipMalloc(&o, telems * 4));
         unsigned long long *d_m; double *d_s;
-        CHK(hipMalloc(&d_m, 24)); d_s = (double *)(d_m + 1);
+        CHK(hipMalloc(&d_m, 32)); d_s = (double *)(d_m + 1);
         auto report = [&](const char *name) {
-            CHK(hipMemset(d_m, 0, 24));
-            k_acc<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, Kil, Gil, pair_stride, pstart, pcap, npairs, tm, d_m, d_s, d_m + 2);
+            CHK(hipMemset(d_m, 0, 32));
+            k_acc<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, Kil, Gil, pair_stride, pstart, pcap, npairs, tm, d_m, d_s, d_m + 2, (double *)(d_m + 3));
             CHK(hipDeviceSynchronize());
-            unsigned long long h[3]; CHK(hipMemcpy(h, d_m, 24, hipMemcpyDeviceToHost));
-            double mx, sm; memcpy(&mx, &h[0], 8); memcpy(&sm, &h[1], 8);
-            printf("accuracy %-30s pairs %d: err / sum|k g|  max %.3e (%.2f x 2^-24)  mean %.3e (%.3f x 2^-24)\n", name, npairs, mx, mx * 16777216.0, sm / (double)h[2], sm / (double)h[2] * 16777216.0);
+            unsigned long long h[4]; CHK(hipMemcpy(h, d_m, 32, hipMemcpyDeviceToHost));
+            double mx, sm, sg; memcpy(&mx, &h[0], 8); memcpy(&sm, &h[1], 8); memcpy(&sg, &h[3], 8);
+            printf("accuracy %-30s pairs %d: err / sum|k g|  max %.3e (%.2f x 2^-24)  mean %.3e (%.3f x 2^-24)  signed mean %.4f x 2^-24\n", name, npairs, mx, mx * 16777216.0, sm / (double)h[2], sm / (double)h[2] * 16777216.0, sg / (double)h[2] * 16777216.0);
         };
         CHK(hipMemset(o, 0xee, telems * 4));
         k_ref<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, (int64_t)tot, Kil, Gil, pair_stride, pstart, pcap, npairs, tm);

@@ -1,7 +1,7 @@
 """GPU: the default single-GPU bench line as the driver runs it (a fresh child process, never an exec from this one): ONE JSON line that carries the headline
 with `roofline` and -- measured in the same invocation, each in a child process of its own -- BASELINE.json's other single-GPU configurations under
 `other_configs`: configs[1] (1 000 landmarks, unknown correspondence, the device-resident measure loop) and the whole configs[4] workload on one GPU
-(40 000 -> 50 000 landmarks, float tiles, the pass in F32 arithmetic).  Short legs here (the figures to quote come from the default run); no CPU baseline."""
+(40 000 -> 50 000 landmarks, float tiles, the pass in F32 arithmetic and in split arithmetic).  Short legs here (the figures to quote come from the default run); no CPU baseline."""
 import json
 import os
 import subprocess
@@ -35,3 +35,10 @@ def test_default_bench_line_carries_the_other_single_gpu_configurations():
     assert r4["bound"] in ("hbm", "mfma") and r4["frac"] == max(r4["roofs"]["hbm"]["frac"], r4["roofs"]["mfma"]["frac"])
     assert r4["pairs_per_launch"] == 64 and 0.3 < r4["roofs"]["hbm"]["frac"] < 1.0 and 0.4 < r4["roofs"]["mfma"]["frac"] < 1.0
     assert c4["steps"] == 9936 and "50000 landmarks" in c4["config"]["workload"]
+    # the same workload with the pass in split arithmetic: bound by HBM, and faster than the F32-arithmetic leg
+    c4s = oc["configs[4] on one GPU, split arithmetic"]
+    assert "error" not in c4s, oc
+    r4s = c4s["roofline"]
+    assert c4s["config"]["state_finite"] and r4s["kernel"] == "k_flush_split3<2>" and r4s["pairs_per_launch"] == 64
+    assert r4s["bound"] == "hbm" and r4s["roofs"]["mfma"]["executed_over_algorithmic_flops"] == 6.0 and r4s["roofs"]["mfma"]["peak"] == 2500.0
+    assert c4s["steps"] == 9936 and c4s["value"] > 1.1 * c4["value"]

@@ -233,8 +233,9 @@ def test_config5_shape_forty_thousand_landmarks_f32_tiles_against_f64_tiles(stor
 
 def test_config5_at_its_real_size_and_length():
     """BASELINE.json configs[4] as SURVEY.md 8d states it, on one GPU: 40 000 landmarks bulk-loaded, every step = predict + append of one
-    new landmark + one correction, UNTIL 50 000 -- 10 000 update-steps -- with float tiles in both arithmetics (F64-arithmetic pass at batch 12,
-    F32-arithmetic pass on the matrix pipe at batch 64) against the F64-tile engine (batch 20) on the same inputs.  The tolerance stated in
+    new landmark + one correction, UNTIL 50 000 -- 10 000 update-steps -- with float tiles in all three arithmetics (F64-arithmetic pass at
+    batch 12, F32-arithmetic pass on the f32 matrix pipe at batch 64, split-arithmetic pass on the bf16 matrix pipe at batch 64) against the
+    F64-tile engine (batch 20) on the same inputs.  The tolerance stated in
     DESIGN.md section 5 for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x, gives 6.2e-8 / 2.1e-8 here: asserted on x, the digests of P, the robot
     rows and the sampled blocks (which include the appended diagonal blocks, the largest entries).  BASELINE.json's 1e-6 is held with a margin of 15."""
     import ctypes, json, os
@@ -250,7 +251,8 @@ def test_config5_at_its_real_size_and_length():
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
     eng = {"f64": Engine(mode="known", capacity=cap, storage="f64", batch=20), "f32": Engine(mode="known", capacity=cap, storage="f32", batch=12),
-           "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64)}
+           "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64),
+           "f32_split": Engine(mode="known", capacity=cap, storage="f32_split", batch=64)}
     for e in eng.values():
         e.load_lowrank_state(x, s, d, U)
     Rc = [.01, 5.0]
@@ -274,7 +276,7 @@ def test_config5_at_its_real_size_and_length():
         assert e.N == cap
     tol_x, tol_P = 1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps
     rec = {"landmarks": [N0, cap], "update_steps": steps, "tolerance_x": tol_x, "tolerance_P": tol_P}
-    for name in ("f32", "f32_mixed"):
+    for name in ("f32", "f32_mixed", "f32_split"):
         ex, ed, er, eb = _f32_against_f64(eng[name], eng["f64"], cap, N0)
         rec[name] = {"deferred_batch": int(eng[name].cfg.batch), "rel_err_x": ex, "rel_err_digest_trace_sum_sumsq": ed, "rel_err_robot_rows": er,
                      "rel_err_sampled_blocks": eb}
@@ -283,7 +285,7 @@ def test_config5_at_its_real_size_and_length():
     if os.path.isdir(out):
         with open(os.path.join(out, "config5_full_length.json"), "w") as fh:
             json.dump(rec, fh)
-    for name in ("f32", "f32_mixed"):
+    for name in ("f32", "f32_mixed", "f32_split"):
         r = rec[name]
         assert r["rel_err_x"] <= tol_x and r["rel_err_digest_trace_sum_sumsq"] <= tol_P and r["rel_err_robot_rows"] <= tol_P \
             and r["rel_err_sampled_blocks"] <= tol_P, rec
@@ -360,8 +362,8 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
     (bulk-loaded diag(d) + U U', the appended panels, one rank-2 term per correction) and evaluates every read EKF_SLAM.m:40-51, :67-98,
     :124-145 make of P from that form in F64 -- pinned to the literal-dense restatement at N <= 200 (tests/test_oracle_factored.py, 1e-11).
     40 000 landmarks bulk-loaded, 224 steps of predict + append + correction (the appended landmarks are corrected too, every 7th step),
-    the F64-tile engine and the mixed-precision engine ("F32 mixed precision with F64 innovation solve": float tiles, the pass in F32
-    arithmetic at batch 64, i.e. the strip kernel) on the same inputs.  Compared: x, the robot rows P(1:3, :), the two rows of seven landmarks
+    the F64-tile engine and the mixed-precision engines ("F32 mixed precision with F64 innovation solve": float tiles, the pass in F32
+    arithmetic at batch 64, i.e. the strip kernel, and in split arithmetic on the bf16 matrix pipe, flush32_split.h) on the same inputs.  Compared: x, the robot rows P(1:3, :), the two rows of seven landmarks
     (bulk-loaded and appended ones) over ALL columns, every landmark's own 2 x 2 block.  Tolerances: F64 tiles 1e-6 relative (BASELINE.json;
     measured 3e-16 .. 2e-15), float tiles: what is kept in F64 (x, the robot rows, the diagonal blocks) the bound DESIGN.md section 5 states
     for K update-steps, 2e-9 + 6e-12 K on P and 1e-9 + 2e-12 K on x; the landmark rows, whose off-diagonal entries ARE floats, 2e-7 of the
@@ -381,7 +383,8 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
     ref = FactoredEKF(cap, "known", max_terms=steps + 4, max_appends=steps + 4)
-    eng = {"f64": Engine(mode="known", capacity=cap, storage="f64", batch=16), "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64)}
+    eng = {"f64": Engine(mode="known", capacity=cap, storage="f64", batch=16), "f32_mixed": Engine(mode="known", capacity=cap, storage="f32_mixed", batch=64),
+           "f32_split": Engine(mode="known", capacity=cap, storage="f32_split", batch=64)}
     for e in list(eng.values()) + [ref]:
         e.load_lowrank_state(x, s, d, U)
     Rc = [.01, 5.0]
@@ -395,11 +398,13 @@ def test_config5_against_the_factored_oracle_at_forty_thousand_landmarks():
         ref.predict(u); ref.append(u, R, w.landmarks[N0 + t], N0 + t + 1); ref.correct([r, b], R, k + 1)
     assert ref.N == cap and all(e.N == cap for e in eng.values())
     assert eng["f32_mixed"].downdate_kernel_name()[0].startswith("k_flush_strip32<")      # three full 64-pair passes ran
+    assert eng["f32_split"].downdate_kernel_name()[0] == "k_flush_split3<2>"
     n = 3 + 2 * cap
     rows = [0, 127, 20000, N0 - 1, N0, N0 + 100, cap - 1]                # landmarks whose two rows are compared over all columns
     Dref = ref.diag_blocks()
     rec = {"landmarks": [N0, cap], "update_steps": steps}
     tol = {"f64": (1e-6, 1e-6, 1e-6), "f32_mixed": (1e-9 + 2e-12 * steps, 2e-9 + 6e-12 * steps, 2e-7)}      # x, F64-kept parts of P, float-stored rows
+    tol["f32_split"] = tol["f32_mixed"]                                  # the split arithmetic is held to the F32 arithmetic's bounds
     for name, e in eng.items():
         ex = rel_err(e.get_x(), ref.x)
         er = rel_err(e.get_P_block(0, 0, 3, n), ref.P_rows(0, 3))
