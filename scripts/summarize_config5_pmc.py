@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Summarise scripts/profile_config5_pmc.sh's counter runs: python scripts/summarize_config5_pmc.py <gpurun_out/tag> <out.json>
+"""Summarise scripts/profile_config5_pmc.sh's counter runs: python scripts/summarize_config5_pmc.py <gpurun_out/tag> <out.json> [storage]
+(an existing <out.json> keeps its legs of other storages: one file holds the F32-arithmetic and the split-arithmetic pass)
 
 Per FULL-batch launch of the pass (64 pairs; the dispatch that applies fewer pairs -- none in this run -- would be dropped by its
 grid): HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB; MI355X_MICROARCH.md "HBM": on gfx950 FETCH_SIZE tallies the 128-byte requests of
@@ -12,7 +13,8 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-KERNELS = ("k_flush_strip32", "k_flush_mfma32")
+storage = sys.argv[3] if len(sys.argv) > 3 else "f32_mixed"
+KERNELS = ("k_flush_strip32", "k_flush_mfma32", "k_flush_split3<")
 
 
 def per_dispatch(name, counter):
@@ -44,7 +46,7 @@ for name in ("fetch", "stats"):
         break
     except (OSError, IndexError, ValueError):
         pass
-leg = {"landmarks": 40000, "batch": 64, "storage": "f32_mixed", "kernel": kern, "pairs_per_launch": 64,
+leg = {"landmarks": 40000, "batch": 64, "storage": storage, "kernel": kern, "pairs_per_launch": 64,
        "dispatches": {"fetch": len(fetch), "write": len(write), "mfma": len(busy), "l2": len(hit)}}
 if line:
     leg["workload"] = line["config"]["workload"]
@@ -69,7 +71,12 @@ if ks:
                                             "max_ms": float(r["MaxNs"]) / 1e6}
 out = {"correction": "gfx950: FETCH_SIZE x2 (128-B requests tallied at 64 B, 16-B/lane streaming reads); WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",
        "source": "scripts/profile_config5_pmc.sh: rocprofv3 --pmc <one group per run> --kernel-include-regex '<the pass>' on "
-                 "scripts/bench_config5.py --landmarks 40000 --steps 192 --warmup 64 --batch 64 --storage f32_mixed",
+                 "scripts/bench_config5.py --landmarks 40000 --steps 192 --warmup 64 --batch 64 --storage <leg's storage>",
        "legs": [leg]}
+try:
+    old = json.load(open(dst))
+    out["legs"] = [l for l in old.get("legs", []) if l.get("storage") != storage] + [leg]
+except (OSError, ValueError):
+    pass
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
