@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // One work-list entry = a 128 x 128 item (flush32_pipe.h: strip_entry, the segments of build_strip_segments); an item = kNCH chunks of two
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
-// tile stores / loads, 32 the tile pieces two per group in the item's first quarter -- never the product kernel
+// tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps -- never the product kernel
 template <int kNCH = 2, int kAbl = 0>
 __global__ __launch_bounds__(512)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
@@ -223,6 +223,11 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     int buf = 0, target = 0;
     StripItem nn = next_item();
     read_frags(buf, 0, fb[0]);
+    // kAbl & 64: s_memtime stamps summed per wavefront -- first chunk | WAIT between the chunks | second chunk | epilogue (the wait for the tile
+    // pieces, the adds) | WAIT at the item's end -- written over the workgroup's dump area at the end ([wave][8] 64-bit counts; [5] = items)
+    unsigned long long seg[6] = { 0, 0, 0, 0, 0, 0 }, tprev = 0;
+    auto mark = [&](int which) { if constexpr ((kAbl & 64) != 0) { const unsigned long long t = stamp_now(); seg[which] += t - tprev; tprev = t; } };
+    if constexpr ((kAbl & 64) != 0) tprev = stamp_now();
     for (;;) {
         const bool newk = nxt.krow0 >= 0 && nxt.krow0 != cur.krow0;
         in_base = reinterpret_cast<const char *>(tiles + cur.toff);
@@ -265,12 +270,15 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             __builtin_amdgcn_sched_barrier(0);
             if (gl == 7 && gi + 1 < NG) {
                 // WAIT between the chunks of an item
+                mark(0);
                 buf ^= 1;
                 target += 8;
                 while (__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
                 read_frags(buf, 0, fb[(gi + 1) & 1]);
+                mark(1);
             }
         }
+        mark(2);
         if (newk) load_k(nxt);
         const float sgn = parity(cur) ? -1.0f : 1.0f;
 #pragma unroll
@@ -279,6 +287,8 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             for (int e = 0; e < 4; ++e) tl[p][e] = fmaf(acc[p >> 2][e][p & 3], sgn, tl[p][e]);     // (exact product: one rounding, as tl + acc)
         zero_acc();
         out_base = reinterpret_cast<const char *>(dst + cur.toff);
+        mark(3);
+        seg[5] += 1;
         if (nxt.krow0 < 0) break;
         cur = nxt;
         nxt = nn;
@@ -287,10 +297,16 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         target += 8;
         while (__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
         read_frags(buf, 0, fb[0]);
+        mark(4);
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p)                                            // the last item's result
         __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
+    if constexpr ((kAbl & 64) != 0) {
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(dump + (size_t)blockIdx.x * (kItem * T)) + wave * 8;
+        if (lane == 0)
+            for (int q = 0; q < 6; ++q) st[q] = seg[q];
+    }
 }
 
 }  // namespace ekf_pipe32

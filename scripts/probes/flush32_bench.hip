@@ -283,6 +283,31 @@ int main(int argc, char **argv) {
         if (npairs > 32) { CHK(hipMemset(o, 0xee, telems * 4)); launch_split(o, true); CHK(hipDeviceSynchronize()); report("k_flush_split3<2>"); }
         CHK(hipFree(o));
     }
+    if (getenv("STAMP") && atoi(getenv("STAMP")) == 3) {
+        // where a wavefront of the split-arithmetic pass spends its cycles (k_flush_split3<2, 64>: stamps in the workgroup's dump area)
+        CHK(hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_split3<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split()));
+        hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(ldm / 256), ekf_pipe32::kKB, 2), dim3(256), 0, 0, (const float *)Kn, (const float *)Gpl, Kb3, Gb3,
+                           pair_stride, ldm, ldm, pstart, pcap, npairs);
+        for (int rep = 0; rep < 2; ++rep)
+            hipLaunchKernelGGL((ekf_pipe32::k_flush_split3<2, 64>), dim3(grid), dim3(512), ekf_pipe32::lds_bytes_split(), 0, (const float *)tiles, tiles, d_segs, nsegs,
+                               (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
+        CHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs(64);
+        double tot6[6] = { 0 };
+        double wv[8][6] = { { 0 } };
+        for (int b = 0; b < grid; ++b) {
+            CHK(hipMemcpy(hs.data(), dump + (size_t)b * 128 * 256, 64 * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 8; ++w)
+                for (int q = 0; q < 6; ++q) { tot6[q] += (double)hs[w * 8 + q]; wv[w][q] += (double)hs[w * 8 + q]; }
+        }
+        const double items = tot6[5] / 8.0 / grid;
+        printf("k_flush_split3<2,stamps> landmarks %lld pairs %d: %.0f items per workgroup; s_memtime ticks (100 MHz) per item and wavefront:\n", (long long)N, npairs, items);
+        printf("  first chunk %.1f | WAIT %.1f | second chunk %.1f | epilogue %.1f | WAIT + first read %.1f   (sum %.1f)\n", tot6[0] / tot6[5], tot6[1] / tot6[5], tot6[2] / tot6[5],
+               tot6[3] / tot6[5], tot6[4] / tot6[5], (tot6[0] + tot6[1] + tot6[2] + tot6[3] + tot6[4]) / tot6[5]);
+        for (int w = 0; w < 8; ++w)
+            printf("  wave %d: %8.1f %8.1f %8.1f %8.1f %8.1f\n", w, wv[w][0] / wv[w][5], wv[w][1] / wv[w][5], wv[w][2] / wv[w][5], wv[w][3] / wv[w][5], wv[w][4] / wv[w][5]);
+        return 0;
+    }
     int rc = 0;
     if (check) {
         CHK(hipMalloc(&out_a, telems * 4)); CHK(hipMalloc(&out_b, telems * 4));
