@@ -11,7 +11,8 @@ classdef ShardedEKF < handle
     methods
         function g = ShardedEKF(mode, capacity, devices, tile, batch, storage, pass_arith)
             % storage: 0 = F64 tiles (default), 1 = F32 tiles with every solve in F64; pass_arith: 1 = the pass over F32 tiles in F32
-            % arithmetic on the matrix pipe ("F32 mixed precision with F64 innovation solve"; include/ekfslam.h, cfg.pass_arith)
+            % arithmetic on the matrix pipe ("F32 mixed precision with F64 innovation solve"; include/ekfslam.h, cfg.pass_arith), 2 = the
+            % same in split arithmetic (three bfloat16 pieces per float operand, bf16 matrix pipe: EKF_ARITH_SPLIT3)
             if nargin < 4, tile = 0; end
             if nargin < 5, batch = 1; end
             if nargin < 6, storage = 0; end

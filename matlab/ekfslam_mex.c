@@ -60,7 +60,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             cfg.world = (int32_t)mxGetScalar(prhs[7]);
         }
         if (nrhs > 8) cfg.storage = (int32_t)mxGetScalar(prhs[8]);    /* EKF_STORE_*: 1 = float tiles (BASELINE configs[4]) */
-        if (nrhs > 9) cfg.pass_arith = (int32_t)mxGetScalar(prhs[9]); /* EKF_ARITH_*: 1 = the pass over float tiles in F32 arithmetic */
+        if (nrhs > 9) cfg.pass_arith = (int32_t)mxGetScalar(prhs[9]); /* EKF_ARITH_*: 1 = the pass over float tiles in F32 arithmetic, 2 = in split arithmetic */
         int32_t rc = ekf_create(&cfg, &h);
         if (rc != EKF_OK) {
             char msg[256];
