@@ -78,6 +78,7 @@ SIGNATURES = {
     "ekf_set_x": (_i32, [_vp, _dp, _i64]),
     "ekf_get_s": (_i32, [_vp, _dp]),
     "ekf_set_s": (_i32, [_vp, _dp, _i64]),
+    "ekf_diag_poke_device_signature": (_i32, [_vp, _i64, _d]),
     "ekf_get_P": (_i32, [_vp, _dp]),
     "ekf_set_P": (_i32, [_vp, _dp, _i64]),
     "ekf_get_P_block": (_i32, [_vp, _i64, _i64, _i64, _i64, _dp]),

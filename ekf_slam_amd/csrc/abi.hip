@@ -1765,6 +1765,16 @@ int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N) {
     return EKF_OK;
 }
 
+int32_t ekf_diag_poke_device_signature(ekf_handle *h, int64_t idx, double value) {
+    if (!h) return EKF_ERR_INVALID_ARG;
+    REQUIRE(h, idx >= 0 && idx < h->N, EKF_ERR_INVALID_ARG, "diag_poke_device_signature: no such landmark");
+    int32_t rc = enter(h);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->st.s + idx, &value, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));      // (`value` is this call's stack)
+    return EKF_OK;
+}
+
 int32_t ekf_get_P(ekf_handle *h, double *P) {
     if (!h || !P) return fail(h, EKF_ERR_INVALID_ARG, "get_P: null argument");
     int32_t rc = enter(h);

@@ -35,7 +35,7 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kKB = 4;                              // k-blocks of 16 pairs the operand planes hold (64 pairs)
 constexpr int kSplitChunk = 2 * 3 * 2 * 4096;       // G of one chunk in LDS: [kbl 2][plane 3][column group 2][e 4][1 KiB]
-constexpr int lds_bytes_split() { return 2 * kSplitChunk; }
+constexpr int lds_bytes_split(int waves = 8) { return 2 * kSplitChunk * waves / 8; }
 inline size_t split_plane_elems(int64_t ldm) { return (size_t)3 * kKB * (size_t)ldm * 32; }      // bf16 elements of Kb (and of Gb)
 
 // float -> three bfloat16 pieces, exact sum (finite inputs; round-to-nearest-even on the bits)
@@ -95,12 +95,18 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
 // tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps -- never the product kernel
-template <int kNCH = 2, int kAbl = 0>
-__global__ __launch_bounds__(512)
+// kW: wavefronts per workgroup.  8: one workgroup per CU, an item = a work-list entry (128 x 128).  4: TWO independent workgroups per CU (the
+// same two wavefronts per SIMD), an item = a 64-column half of an entry (both halves by the same workgroup, one after the other: -K stays):
+// the two workgroups of a CU share no synchronisation, so their tile-traffic and matrix phases drift apart and interleave on each SIMD.
+template <int kNCH = 2, int kAbl = 0, int kW = 8>
+__global__ __launch_bounds__(64 * kW)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                     const uint16_t *__restrict__ Kb, const uint16_t *__restrict__ Gb, int64_t ldm, TileMap tm, float *__restrict__ dump) {
     constexpr int T = 256, NG = 8 * kNCH, NKBU = 2 * kNCH;                 // groups (k-block, column block) and k-blocks per item
     static_assert(kNCH == 1 || kNCH == 2, "chunks per item");
+    static_assert(kW == 8 || kW == 4, "wavefronts per workgroup");
+    constexpr int kCG = kW / 4;                                            // 64-column groups per item
+    constexpr uint32_t kChunk = 2 * 3 * kCG * 4096;                        // G of one chunk in LDS: [kbl 2][plane 3][column group kCG][e 4][1 KiB]
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,8 +129,10 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     };
     ent = load_entries(0);
     int nnext = 0;
+    StripItem half2; half2.toff = 0; half2.krow0 = -1; half2.gcol0 = 0;    // kW == 4: the second 64-column half of the entry handed out last
     auto next_item = [&]() {
         StripItem q; q.toff = 0; q.krow0 = -1; q.gcol0 = 0;
+        if (kW == 4 && half2.krow0 >= 0) { q = half2; half2.krow0 = -1; return q; }
         while (nnext < nent) {
             const int n = nnext++;
             if (n - nbase >= 64) { nbase = n; ent = load_entries(nbase); }
@@ -133,6 +141,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             q.toff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(ent.y, n - nbase) << 32) | (uint32_t)__builtin_amdgcn_readlane(ent.x, n - nbase));
             q.krow0 = kr;
             q.gcol0 = __builtin_amdgcn_readlane(ent.w, n - nbase);
+            if (kW == 4) { half2 = q; half2.toff += 64; half2.gcol0 += 64; }
             break;
         }
         return q;
@@ -144,7 +153,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     // wavefront w: rows 32 (w >> 1) .. + 31, columns 64 (w & 1) .. + 63 of the item: two row blocks x four column blocks of 16 x 16; lane
     // (lr, lc): A = -K(row 32 wi + 16 rb + lc, k 8 lr ..) in ka[rb][kb][p]; B = G(k 8 lr .., column 64 wj + 4 lc + e); accumulators acc[rb][e][i] =
     // entry (row 32 wi + 16 rb + 4 lr + i, column 64 wj + 4 lc + e): the lane's tile piece 4 rb + i is sixteen consecutive bytes of that row
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = kW == 8 ? wave >> 1 : wave, wj = kW == 8 ? wave & 1 : 0;
     const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * T + 64 * wj + 4 * lc) * 4;
     bf8_t ka[2][NKBU][3];
     auto load_k = [&](const StripItem &q) {
@@ -164,8 +173,8 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     u4_t gq[6] = {};
     const int64_t ncg = ldm >> 6;
     auto g_src = [&](const StripItem &q, int ch, int j) {
-        const int t = wave + 8 * j, blk = t >> 2, e = t & 3;
-        const int cgl = blk & 1, kp = blk >> 1, kbl = kp / 3, p = kp - 3 * kbl;
+        const int t = wave + kW * j, blk = t >> 2, e = t & 3;
+        const int cgl = kCG == 2 ? blk & 1 : 0, kp = kCG == 2 ? blk >> 1 : blk, kbl = kp / 3, p = kp - 3 * kbl;
         const int64_t cg = ((q.krow0 >= 0 ? q.gcol0 : 0) >> 6) + cgl;
         return reinterpret_cast<const char *>(Gb) + ((((int64_t)p * kKB + 2 * ch + kbl) * ncg + cg) * 4 + e) * 1024 + lane * 16;
     };
@@ -179,7 +188,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     auto parity = [&](const StripItem &q) { return (uint32_t)(((q.krow0 ^ q.gcol0) >> 7) & 1); };
     auto write_g = [&](int buf, int j, uint32_t flip) {
         const uint32_t fm = flip ? 0x80008000u : 0u;
-        *reinterpret_cast<u4_t *>(smem + (uint32_t)buf * kSplitChunk + (uint32_t)(wave + 8 * j) * 1024 + (uint32_t)lane * 16) = gq[j] ^ u4_t{ fm, fm, fm, fm };
+        *reinterpret_cast<u4_t *>(smem + (uint32_t)buf * kChunk + (uint32_t)(wave + kW * j) * 1024 + (uint32_t)lane * 16) = gq[j] ^ u4_t{ fm, fm, fm, fm };
     };
     // Tile traffic as in k_flush_strip32: ONE register buffer of eight 16-byte pieces carries two items at a time -- in the item's first
     // chunk each piece's register first gives up the PREVIOUS item's finished entries (a store), then takes the CURRENT item's tile value (a
@@ -198,9 +207,9 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     for (int p = 0; p < 8; ++p) tl[p] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
     bf8_t fb[2][3];                                                        // fragment sets: group gi in set gi & 1
     auto read_frags = [&](int buf, int gl, bf8_t (&b)[3]) {                // gl: group inside the chunk (kbl = gl >> 2, e = gl & 3)
-        const uint32_t o = (uint32_t)buf * kSplitChunk + (uint32_t)((gl >> 2) * 3 * 2 + wj) * 4096 + (uint32_t)(gl & 3) * 1024 + (uint32_t)lane * 16;
+        const uint32_t o = (uint32_t)buf * kChunk + (uint32_t)((gl >> 2) * 3 * kCG + wj) * 4096 + (uint32_t)(gl & 3) * 1024 + (uint32_t)lane * 16;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf8_t *>(smem + o + (uint32_t)p * 8192);
+        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf8_t *>(smem + o + (uint32_t)p * (kCG * 4096));
     };
     auto mfma_group = [&](int kb, int e, const bf8_t (&b)[3]) {
         // the six partial products, smallest class first; the two row blocks alternate (two independent chains)
@@ -272,7 +281,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 // WAIT between the chunks of an item
                 mark(0);
                 buf ^= 1;
-                target += 8;
+                target += kW;
                 while (__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
                 read_frags(buf, 0, fb[(gi + 1) & 1]);
                 mark(1);
@@ -294,7 +303,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         nxt = nn;
         nn = next_item();
         buf ^= 1;
-        target += 8;
+        target += kW;
         while (__hip_atomic_load(&arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
         read_frags(buf, 0, fb[0]);
         mark(4);

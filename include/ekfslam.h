@@ -257,6 +257,13 @@ int32_t ekf_get_x(ekf_handle *h, double *x /* 3+2N */);
 int32_t ekf_set_x(ekf_handle *h, const double *x, int64_t n);
 int32_t ekf_get_s(ekf_handle *h, double *s /* N */);
 int32_t ekf_set_s(ekf_handle *h, const double *s, int64_t N);
+/* Diagnostic -- a fault injector for tests of the device-resident measure loop's verification, of no use to a host: overwrites the DEVICE copy
+ * of signature idx (0-based) and leaves the host mirror alone.  The next ekf_measure whose association involves that landmark then queues its
+ * launches from a prediction the device contradicts; every launch stays inside the state (a correction falls back to the predicted landmark,
+ * a predicted append appends), ekf_measure itself returns EKF_OK (it waits for nothing),
+ * and the FIRST synchronising call afterwards (ekf_sync, any getter, ekf_flush ...) returns EKF_ERR_STATE once, with the decision and the
+ * prediction in ekf_last_error: from there on the state is no longer the reference's -- reload it (ekf_set_x / _P / _s, a checkpoint). */
+int32_t ekf_diag_poke_device_signature(ekf_handle *h, int64_t idx, double value);
 /* Dense n x n column-major P.  set_P stores the lower triangle (P is a covariance: symmetric).  On a shard
  * (world > 1) get_P / get_P_block return NaN for landmark-block entries held by another shard. */
 int32_t ekf_get_P(ekf_handle *h, double *P);

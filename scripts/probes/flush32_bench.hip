@@ -193,7 +193,7 @@ int main(int argc, char **argv) {
     };
     typedef void (*fns_t)(const float *, float *, const int4 *, int64_t, const float *, const float *, int64_t, int64_t, int, int, int, TileMap, float *, unsigned long long *);
     float *dump;
-    CHK(hipMalloc(&dump, (size_t)grid * 128 * 256 * 4));
+    CHK(hipMalloc(&dump, (size_t)grid * 2 * 128 * 256 * 4));
     struct VarS { const char *name; fns_t fn; int lds, threads, D; };
     const VarS vs[] = {
         { "k_flush_strip32<8>", ekf_pipe32::k_flush_strip32<8>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
@@ -211,25 +211,29 @@ int main(int argc, char **argv) {
     CHK(hipMemset(Kb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2)); CHK(hipMemset(Gb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2));
     typedef void (*fsp_t)(const float *, float *, const int4 *, int64_t, const uint16_t *, const uint16_t *, int64_t, TileMap, float *);
     // ABL=1: the ablations beside the kernel (diagnostic instances: results are wrong by construction)
-    struct VarP { const char *name; fsp_t fn; };
+    struct VarP { const char *name; fsp_t fn; int waves; };
     const VarP vp[] = {
-        { "k_flush_split3<2>", ekf_pipe32::k_flush_split3<2, 0> },
-        { "  abl: no tile stores", ekf_pipe32::k_flush_split3<2, 1> },
-        { "  abl: no tile loads", ekf_pipe32::k_flush_split3<2, 2> },
-        { "  abl: no tile traffic", ekf_pipe32::k_flush_split3<2, 3> },
-        { "  abl: no G loads", ekf_pipe32::k_flush_split3<2, 4> },
-        { "  abl: no traffic at all", ekf_pipe32::k_flush_split3<2, 7> },
-        { "  var: plain tile stores", ekf_pipe32::k_flush_split3<2, 8> },
-        { "  var: plain tile loads", ekf_pipe32::k_flush_split3<2, 16> },
-        { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> },
-        { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> },
+        { "k_flush_split3<2>", ekf_pipe32::k_flush_split3<2, 0>, 8 },
+        { "k_flush_split3<2,0,4>: two workgroups of four wavefronts per CU", ekf_pipe32::k_flush_split3<2, 0, 4>, 4 },
+        { "  abl: no tile stores", ekf_pipe32::k_flush_split3<2, 1> , 8 },
+        { "  abl: no tile loads", ekf_pipe32::k_flush_split3<2, 2> , 8 },
+        { "  abl: no tile traffic", ekf_pipe32::k_flush_split3<2, 3> , 8 },
+        { "  abl: no G loads", ekf_pipe32::k_flush_split3<2, 4> , 8 },
+        { "  abl: no traffic at all", ekf_pipe32::k_flush_split3<2, 7> , 8 },
+        { "  <2,.,4> abl: no tile stores", ekf_pipe32::k_flush_split3<2, 1, 4>, 4 },
+        { "  <2,.,4> abl: no tile traffic", ekf_pipe32::k_flush_split3<2, 3, 4>, 4 },
+        { "  <2,.,4> abl: no traffic at all", ekf_pipe32::k_flush_split3<2, 7, 4>, 4 },
+        { "  var: plain tile stores", ekf_pipe32::k_flush_split3<2, 8> , 8 },
+        { "  var: plain tile loads", ekf_pipe32::k_flush_split3<2, 16> , 8 },
+        { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> , 8 },
+        { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> , 8 },
     };
-    const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 1;
-    for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split()));
+    const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 2;
+    for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split(vp[v].waves)));
     auto launch_split = [&](float *dstp, bool cut, int v = 0) {
         if (cut) hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(ldm / 256), ekf_pipe32::kKB, 2), dim3(256), 0, 0, (const float *)Kn, (const float *)Gpl, Kb3, Gb3,
                                     pair_stride, ldm, ldm, pstart, pcap, npairs);
-        hipLaunchKernelGGL(vp[v].fn, dim3(grid), dim3(512), ekf_pipe32::lds_bytes_split(), 0, (const float *)tiles, dstp, d_segs, nsegs,
+        hipLaunchKernelGGL(vp[v].fn, dim3(grid * 8 / vp[v].waves), dim3(64 * vp[v].waves), ekf_pipe32::lds_bytes_split(vp[v].waves), 0, (const float *)tiles, dstp, d_segs, nsegs,
                            (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
     };
     auto strip_ok = [&](int v) { return (npairs + 7) / 8 == 8; };      // (instantiated for eight stages: 57-64 pairs)
@@ -280,8 +284,30 @@ int main(int argc, char **argv) {
         k_ref<<<(unsigned)(tot * (T * T / 256)), 256>>>(tiles, o, d_flat, (int64_t)tot, Kil, Gil, pair_stride, pstart, pcap, npairs, tm);
         CHK(hipDeviceSynchronize()); report("fmaf chain (reference)");
         CHK(hipMemset(o, 0xee, telems * 4)); launch_old(o); CHK(hipDeviceSynchronize()); report("k_flush_mfma32");
-        if (npairs > 32) { CHK(hipMemset(o, 0xee, telems * 4)); launch_split(o, true); CHK(hipDeviceSynchronize()); report("k_flush_split3<2>"); }
+        if (npairs > 32) { CHK(hipMemset(o, 0xee, telems * 4)); launch_split(o, true, 0); CHK(hipDeviceSynchronize()); report("k_flush_split3<2>"); }
+        if (npairs > 32) { CHK(hipMemset(o, 0xee, telems * 4)); launch_split(o, true, 1); CHK(hipDeviceSynchronize()); report("k_flush_split3<2,0,4>"); }
         CHK(hipFree(o));
+    }
+    if (getenv("STAMP") && atoi(getenv("STAMP")) == 4) {
+        CHK(hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_split3<2, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split(4)));
+        hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(ldm / 256), ekf_pipe32::kKB, 2), dim3(256), 0, 0, (const float *)Kn, (const float *)Gpl, Kb3, Gb3,
+                           pair_stride, ldm, ldm, pstart, pcap, npairs);
+        for (int rep = 0; rep < 2; ++rep)
+            hipLaunchKernelGGL((ekf_pipe32::k_flush_split3<2, 64, 4>), dim3(2 * grid), dim3(256), ekf_pipe32::lds_bytes_split(4), 0, (const float *)tiles, tiles, d_segs, nsegs,
+                               (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
+        CHK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hs(32);
+        double wv[4][6] = { { 0 } }, tot6[6] = { 0 };
+        for (int b = 0; b < 2 * grid; ++b) {
+            CHK(hipMemcpy(hs.data(), dump + (size_t)b * 128 * 256, 32 * 8, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 4; ++w)
+                for (int q = 0; q < 6; ++q) { tot6[q] += (double)hs[w * 8 + q]; wv[w][q] += (double)hs[w * 8 + q]; }
+        }
+        printf("k_flush_split3<2,stamps,4> landmarks %lld pairs %d: ticks per (half-)item and wavefront: first chunk %.1f | WAIT %.1f | second chunk %.1f | epilogue %.1f | WAIT + first read %.1f   (sum %.1f)\n",
+               (long long)N, npairs, tot6[0] / tot6[5], tot6[1] / tot6[5], tot6[2] / tot6[5], tot6[3] / tot6[5], tot6[4] / tot6[5], (tot6[0] + tot6[1] + tot6[2] + tot6[3] + tot6[4]) / tot6[5]);
+        for (int w = 0; w < 4; ++w)
+            printf("  wave %d: %8.1f %8.1f %8.1f %8.1f %8.1f\n", w, wv[w][0] / wv[w][5], wv[w][1] / wv[w][5], wv[w][2] / wv[w][5], wv[w][3] / wv[w][5], wv[w][4] / wv[w][5]);
+        return 0;
     }
     if (getenv("STAMP") && atoi(getenv("STAMP")) == 3) {
         // where a wavefront of the split-arithmetic pass spends its cycles (k_flush_split3<2, 64>: stamps in the workgroup's dump area)

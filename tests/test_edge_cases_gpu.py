@@ -168,3 +168,51 @@ def test_signature_index_of_the_host_mirror_agrees_with_the_device_on_ties_and_t
     np.testing.assert_array_equal(e.get_s(), ref.get_s())
     np.testing.assert_array_equal(e.get_x(), ref.get_x())
     np.testing.assert_array_equal(e.get_P(), ref.get_P())
+
+
+@pytest.mark.parametrize("kind", ["correction_contradicted", "append_contradicted"])
+def test_device_loop_mismatch_is_reported_once_at_the_next_synchronising_call(kind):
+    """include/ekfslam.h, cfg.device_assoc = 3: the host queues a scan's launches from its mirror's prediction of every association and
+    waits for nothing; what the device decided is compared afterwards.  The two cannot differ unless the device's signatures changed behind
+    the library's back -- which ekf_diag_poke_device_signature does on purpose.  What the caller sees: ekf_measure returns EKF_OK; the
+    first synchronising call returns EKF_ERR_STATE exactly once, naming both decisions; every launch stayed inside the state (finite, N as the
+    host predicted); the handle stays usable and a state reload makes it the reference's again (bit-identical to a fresh engine)."""
+    from ekf_slam_amd import Engine, _lib as L
+    from ekf_slam_amd._lib import EkfError
+    rng = np.random.default_rng(9)
+    N = 40
+    n = 3 + 2 * N
+    x = np.concatenate([[0.3, -0.2, 40.0], rng.uniform(-30, 30, size=2 * N)])
+    U = rng.normal(0, 0.05, size=(n, 4))
+    P = np.diag(rng.uniform(0.01, 0.1, size=n)) + U @ U.T
+    s = np.arange(1, N + 1.0)
+    e = Engine(mode="uc", capacity=N + 8, tile=16, batch=4, device_assoc=3)
+    e.set_state(x, P, s)
+    u = [0.1, 2.0]
+    idx, loc = np.array([N + 1.0]), np.array([[5.0, 6.0]])
+    if kind == "correction_contradicted":
+        # the host's mirror matches signature 7 to landmark 7; on the device that landmark's signature is now far away: nothing passes
+        assert e.lib.ekf_diag_poke_device_signature(e.h, 6, 1000.0) == L.EKF_OK
+        rows = [[12.0, 30.0, 7.0]]
+    else:
+        # the host's mirror finds no landmark for signature 500 and queues an append; on the device landmark 3 carries that signature
+        assert e.lib.ekf_diag_poke_device_signature(e.h, 2, 500.0) == L.EKF_OK
+        rows = [[12.0, 30.0, 500.0]]
+    e.predict(u)
+    e.measure(rows, u, idx, loc)                                              # EKF_OK: nothing is waited for
+    with pytest.raises(EkfError) as ei:
+        e.sync()
+    assert ei.value.status == L.EKF_ERR_STATE and "device association decided" in str(ei.value) and "predicted" in str(ei.value)
+    e.sync()                                                                  # reported once
+    assert e.N == (N if kind == "correction_contradicted" else N + 1)         # what the host queued ran, inside the state
+    assert np.isfinite(e.get_x()).all() and np.isfinite(e.get_P()).all()
+    # reload: the reference's state again
+    fresh = Engine(mode="uc", capacity=N + 8, tile=16, batch=4, device_assoc=3)
+    for g in (e, fresh):
+        g.set_state(x, P, s)
+        g.predict(u)
+        g.measure([[12.0, 30.0, 7.0], [3.0, 200.0, 99.0]], u, idx, loc)
+        g.sync()
+    assert e.N == fresh.N == N + 1
+    np.testing.assert_array_equal(e.get_x(), fresh.get_x())
+    np.testing.assert_array_equal(e.get_P(), fresh.get_P())
