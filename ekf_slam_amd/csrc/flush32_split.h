@@ -234,7 +234,9 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     read_frags(buf, 0, fb[0]);
     // kAbl & 64: s_memtime stamps summed per wavefront -- first chunk | WAIT between the chunks | second chunk | epilogue (the wait for the tile
     // pieces, the adds) | WAIT at the item's end -- written over the workgroup's dump area at the end ([wave][8] 64-bit counts; [5] = items)
-    unsigned long long seg[6] = { 0, 0, 0, 0, 0, 0 }, tprev = 0;
+    unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tprev = 0;          // [6], [7]: inside the chunks -- the G block, the tile pieces
+    auto sub_mark = [&](int which, unsigned long long t0) { if constexpr ((kAbl & 64) != 0) seg[which] += stamp_now() - t0; };
+    auto sub_start = [&]() { unsigned long long t = 0; if constexpr ((kAbl & 64) != 0) t = stamp_now(); return t; };
     auto mark = [&](int which) { if constexpr ((kAbl & 64) != 0) { const unsigned long long t = stamp_now(); seg[which] += t - tprev; tprev = t; } };
     if constexpr ((kAbl & 64) != 0) tprev = stamp_now();
     for (;;) {
@@ -255,6 +257,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 // tile traffic.  (Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load and store;
                 // here the G pieces waited for are older than every tile piece in flight.  Spread over the chunk between the tile pieces --
                 // k_flush_strip32's order -- the pass measured the same, 5.18 ms at 40 000 landmarks: round4_tuning.md 53.)
+                const unsigned long long tg0 = sub_start();
                 const uint32_t flip_next = (kNCH == 2 && ch == 0) ? parity(cur) : parity(nxt);      // whose G these pieces are
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -264,9 +267,11 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                     else load_g(nn, 0, j);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                sub_mark(6, tg0);
             }
             mfma_group(2 * ch + (gl >> 2), gl & 3, fb[gi & 1]);
             if ((kAbl & 32) ? gi < 4 : gi < 8) {
+                const unsigned long long tt0 = sub_start();
                 // the tile pieces: the register first gives up the PREVIOUS item's finished entries, then takes this item's tile value
 #pragma unroll
                 for (int p = (kAbl & 32) ? 2 * gi : gi; p < ((kAbl & 32) ? 2 * gi + 2 : gi + 1); ++p) {
@@ -275,6 +280,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                     if (!(kAbl & 1)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
                     if (!(kAbl & 2)) { if (kAbl & 16) tl[p] = *pi; else tl[p] = __builtin_nontemporal_load(pi); }
                 }
+                sub_mark(7, tt0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (gl == 7 && gi + 1 < NG) {
@@ -314,7 +320,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     if constexpr ((kAbl & 64) != 0) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(dump + (size_t)blockIdx.x * (kItem * T)) + wave * 8;
         if (lane == 0)
-            for (int q = 0; q < 6; ++q) st[q] = seg[q];
+            for (int q = 0; q < 8; ++q) st[q] = seg[q];
     }
 }
 

@@ -319,19 +319,19 @@ int main(int argc, char **argv) {
                                (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
         CHK(hipDeviceSynchronize());
         std::vector<unsigned long long> hs(64);
-        double tot6[6] = { 0 };
-        double wv[8][6] = { { 0 } };
+        double tot6[8] = { 0 };
+        double wv[8][8] = { { 0 } };
         for (int b = 0; b < grid; ++b) {
             CHK(hipMemcpy(hs.data(), dump + (size_t)b * 128 * 256, 64 * 8, hipMemcpyDeviceToHost));
             for (int w = 0; w < 8; ++w)
-                for (int q = 0; q < 6; ++q) { tot6[q] += (double)hs[w * 8 + q]; wv[w][q] += (double)hs[w * 8 + q]; }
+                for (int q = 0; q < 8; ++q) { tot6[q] += (double)hs[w * 8 + q]; wv[w][q] += (double)hs[w * 8 + q]; }
         }
         const double items = tot6[5] / 8.0 / grid;
-        printf("k_flush_split3<2,stamps> landmarks %lld pairs %d: %.0f items per workgroup; s_memtime ticks (100 MHz) per item and wavefront:\n", (long long)N, npairs, items);
-        printf("  first chunk %.1f | WAIT %.1f | second chunk %.1f | epilogue %.1f | WAIT + first read %.1f   (sum %.1f)\n", tot6[0] / tot6[5], tot6[1] / tot6[5], tot6[2] / tot6[5],
-               tot6[3] / tot6[5], tot6[4] / tot6[5], (tot6[0] + tot6[1] + tot6[2] + tot6[3] + tot6[4]) / tot6[5]);
+        printf("k_flush_split3<2,stamps> landmarks %lld pairs %d: %.0f items per workgroup; s_memtime ticks per item and wavefront:\n", (long long)N, npairs, items);
+        printf("  first chunk %.1f | WAIT %.1f | second chunk %.1f | epilogue %.1f | WAIT + first read %.1f   (sum %.1f); inside the chunks: the two G blocks %.1f, the eight tile pieces %.1f\n", tot6[0] / tot6[5], tot6[1] / tot6[5], tot6[2] / tot6[5],
+               tot6[3] / tot6[5], tot6[4] / tot6[5], (tot6[0] + tot6[1] + tot6[2] + tot6[3] + tot6[4]) / tot6[5], tot6[6] / tot6[5], tot6[7] / tot6[5]);
         for (int w = 0; w < 8; ++w)
-            printf("  wave %d: %8.1f %8.1f %8.1f %8.1f %8.1f\n", w, wv[w][0] / wv[w][5], wv[w][1] / wv[w][5], wv[w][2] / wv[w][5], wv[w][3] / wv[w][5], wv[w][4] / wv[w][5]);
+            printf("  wave %d: %8.1f %8.1f %8.1f %8.1f %8.1f | %8.1f %8.1f\n", w, wv[w][0] / wv[w][5], wv[w][1] / wv[w][5], wv[w][2] / wv[w][5], wv[w][3] / wv[w][5], wv[w][4] / wv[w][5], wv[w][6] / wv[w][5], wv[w][7] / wv[w][5]);
         return 0;
     }
     int rc = 0;
