@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // One work-list entry = a 128 x 128 item (flush32_pipe.h: strip_entry, the segments of build_strip_segments); an item = kNCH chunks of two
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
-// tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps -- never the product kernel
+// tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps, 256 the younger wavefronts' G block four
+// groups later -- never the product kernel
 // kW: wavefronts per workgroup.  8: one workgroup per CU, an item = a work-list entry (128 x 128).  4: TWO independent workgroups per CU (the
 // same two wavefronts per SIMD), an item = a 64-column half of an entry (both halves by the same workgroup, one after the other: -K stays):
 // the two workgroups of a CU share no synchronisation, so their tile-traffic and matrix phases drift apart and interleave on each SIMD.
@@ -252,7 +253,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (gl == 0) {
+            if ((kAbl & 256) ? ((gl == 0 && wave < kW / 2) || (gl == 4 && wave >= kW / 2)) : gl == 0) {     // (probe variant 256: the younger wavefronts' G block four groups later)
                 // The next chunk's G into the buffer the last WAIT freed, the chunk after it on its way: all six pieces here, in front of the chunk's
                 // tile traffic.  (Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load and store;
                 // here the G pieces waited for are older than every tile piece in flight.  Spread over the chunk between the tile pieces --

@@ -227,6 +227,7 @@ int main(int argc, char **argv) {
         { "  var: plain tile loads", ekf_pipe32::k_flush_split3<2, 16> , 8 },
         { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> , 8 },
         { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> , 8 },
+        { "  var: the younger wavefronts' G block four groups later", ekf_pipe32::k_flush_split3<2, 256> , 8 },
     };
     const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 2;
     for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split(vp[v].waves)));
