@@ -293,7 +293,7 @@ def test_config5_at_its_real_size_and_length():
         e.close()
 
 
-@pytest.mark.parametrize("storage,batch", [("f32", 12), ("f32_mixed", 32)])
+@pytest.mark.parametrize("storage,batch", [("f32", 12), ("f32_mixed", 32), ("f32_split", 64)])
 def test_config5_shape_eight_shards_equal_the_single_gpu_engine_bitwise(storage, batch):
     """BASELINE.json configs[4] is an 8-GPU configuration: 40 000 landmarks, float tiles, streaming append, P split over 8 shards (all on the one
     test GPU, one process: ekf_exchange_local; the kernels are the ones a multi-GPU run launches).  Two batches of predict + append + correction with
@@ -330,6 +330,9 @@ def test_config5_shape_eight_shards_equal_the_single_gpu_engine_bitwise(storage,
             e.append(u, R, w.landmarks[N0 + t], N0 + t + 1)
             e.correct([r, b], R, k)
     assert one.N == g.N == cap
+    if storage == "f32_split":                                 # two full 64-pair passes ran in split arithmetic, on the plain engine and on every shard
+        assert one.downdate_kernel_name() == ("k_flush_split3<2>", 64)
+        assert all(e.downdate_kernel_name() == ("k_flush_split3<2>", 64) for e in g.shards)
     plan = [3, 39999, N0 + 5, 3, 20000, cap - 1, 12345, 77][:min(batch, 8)]
     g.flush(); one.flush()
     g.prefetch_rows(sorted(set(plan)))
