@@ -5,7 +5,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("storage,tile,batch", [("f64", 16, 1), ("f64", 0, 8), ("f32", 0, 4), ("f32_mixed", 0, 6)])
+@pytest.mark.parametrize("storage,tile,batch", [("f64", 16, 1), ("f64", 0, 8), ("f32", 0, 4), ("f32_mixed", 0, 6), ("f32_split", 0, 40)])
 def test_checkpoint_resume_is_bit_identical(tmp_path, storage, tile, batch):
     from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
     from ekf_slam_amd.trajectory import TrajectoryLog
