@@ -143,3 +143,27 @@ def test_split_arithmetic_shrink_and_reload_leave_no_stale_planes(oracle_lib):
     assert used.N == fresh.N == N0 + 10
     np.testing.assert_array_equal(used.get_x(), fresh.get_x())
     np.testing.assert_array_equal(used.get_P(), fresh.get_P())
+
+
+def test_split_arithmetic_unknown_correspondence_device_loop(oracle_lib):
+    """EKF_SLAM_UC.measure (EKF_SLAM_UC.m:107-151) on the split-arithmetic engine at batch 40: the device-resident loop's decisions equal the
+    host-decided mode's (the association reads x, s, the strip and the F64 diagonal blocks: nothing the pass's arithmetic touches), so the
+    two states are equal bit for bit -- and both are on the oracle."""
+    from ekf_slam_amd.slam import EKF_SLAM_UC, Landmark
+    from ekf_slam_amd.world import SyntheticLandmark, make_run
+    from oracle.ekf_structured import StructuredEKF
+    _, run = make_run(150, 7, 16, policy="nearest", m=6)
+    dev = EKF_SLAM_UC(capacity=160, batch=40, storage="f32_split")
+    host = EKF_SLAM_UC(capacity=160, batch=40, storage="f32_split", device_assoc=0)
+    ref = StructuredEKF(160, "uc")
+    ld, lh, lr = Landmark('SYNTHETIC'), Landmark('SYNTHETIC'), SyntheticLandmark()
+    split_passes = 0
+    for u, scan in run:
+        for e, l in ((dev, ld), (host, lh), (ref, lr)):
+            e.predict(u); e.measure(scan, u, l)
+        split_passes += dev._e.downdate_kernel_name() == ("k_flush_split3<2>", 40)
+    assert split_passes > 0                                  # passes of 40 pairs ran in split arithmetic
+    assert dev._e.N == host._e.N == ref.N == 150
+    np.testing.assert_array_equal(dev.x, host.x)
+    np.testing.assert_array_equal(dev.P, host.P)
+    assert rel_err(dev.x, ref.x) < TOL_X and rel_err(dev.P, ref.P) < TOL_P
