@@ -4,11 +4,13 @@
 //
 // Every float operand is cut EXACTLY into three bfloat16 pieces (a = a1 + a2 + a3: 3 x 8 significant bits = the float's 24, each piece
 // the round-to-nearest bfloat16 of what the previous ones left), and a product a b is evaluated as the six partial products
-//     a3 b1 + a2 b2 + a1 b3 + a2 b1 + a1 b2 + a1 b1                (dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-26 |a b|)
+//     a3 b1 + a2 b2 + a1 b3 + a2 b1 + a1 b2 + a1 b1        (dropped: a2 b3 + a3 b2 + a3 b3: at most 2^-23 |a b|, 0.09 x 2^-24 |a b| in the root mean square)
 // each of them EXACT in float (8 x 8 bits), summed in float by v_mfma_f32_16x16x32_bf16, smallest class first, from a ZERO accumulator;
-// the float tile value is added once at the end, as in the F32-arithmetic pass (flush32_mfma.h).  What the operands lose is a quarter of
-// one float rounding per product; what remains is the accumulation error of a float sum of 2m terms -- the error of the fmaf chain, measured
-// entry by entry against an F64 sum by scripts/probes/flush32_bench.hip (ACC=1).  The result is NOT bit-identical to the fmaf chain.
+// the float tile value is added once at the end, as in the F32-arithmetic pass (flush32_mfma.h).  The pieces themselves lose nothing; the three
+// dropped partial products are bounded by |a2| <= 2^-8 |a|, |a3| <= 2^-16 |a| (tests/test_split3_arith_cpu.py restates the cut in NumPy: exact sums,
+// exact partial products, the dropped part measured); the rest is the accumulation error of a float sum -- 24 accumulator roundings per entry
+// where the fmaf chain has 128.  Measured entry by entry against an F64 sum (scripts/probes/flush32_bench.hip ACC=1) the split sum is CLOSER than
+// the fmaf chain's.  The result is NOT bit-identical to the fmaf chain.
 // Why: the bf16 instruction retires 16x the flops per cycle of v_mfma_f32_16x16x4_f32; at six partial products that is 2.7x the F32
 // matrix pipe, which moves the 64-pair pass from the matrix pipe's roof (7.3 ms at 40 000 landmarks) to the HBM roof.
 //

@@ -122,7 +122,7 @@ typedef struct ekf_config {
                                     (the whole configs[4] workload, 40 000 -> 50 000 landmarks: 2e-8).
                                     EKF_ARITH_SPLIT3 (same preconditions): the same float copies, each cut EXACTLY into three bfloat16
                                     pieces (3 x 8 significant bits) in front of the pass; a product is the sum of the six partial
-                                    products that matter (what is dropped is below 2^-26 of it -- a quarter of one float rounding),
+                                    products that matter (what is dropped is at most 2^-23 of it, 0.09 x 2^-24 in the root mean square),
                                     each exact in float, summed in float on the bf16 matrix pipe from zero, then added to the tile
                                     value once.  Same error class as EKF_ARITH_F32 (a float sum of 2m terms; measured against an F64
                                     sum beside the fmaf chain: DESIGN.md section 5), NOT the same bits; at 33-64 pending pairs the

@@ -1,6 +1,7 @@
 """GPU: cfg.pass_arith = EKF_ARITH_SPLIT3 ("f32_split") -- configs[4]'s mixed precision with the pass over the float tiles on the BF16
 matrix pipe: every float operand (the float copies of the pending pairs the F32-arithmetic pass reads) is cut EXACTLY into three
-bfloat16 pieces, a product is the sum of six partial products (each exact in float; what is dropped is below 2^-26 of the product),
+bfloat16 pieces, a product is the sum of six partial products (each exact in float; what is dropped is at most 2^-23 of the product, 0.09 x 2^-24
+in the root mean square: tests/test_split3_arith_cpu.py),
 summed in float from zero, added to the float tile value once (ekf_slam_amd/csrc/flush32_split.h; EKF_SLAM.m:145 x m).
 
 What is asserted, and against what:
