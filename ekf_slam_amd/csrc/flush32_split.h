@@ -97,17 +97,23 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
 // tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps, 256 the younger wavefronts' G block four
-// groups later -- never the product kernel
+// groups later, 512 the tile STORES two per group in the item's first quarter (with kLd0 > 0), 2048 the results stored in one burst at the
+// epilogue -- never the product kernel
 // kW: wavefronts per workgroup.  8: one workgroup per CU, an item = a work-list entry (128 x 128).  4: TWO independent workgroups per CU (the
 // same two wavefronts per SIMD), an item = a 64-column half of an entry (both halves by the same workgroup, one after the other: -K stays):
 // the two workgroups of a CU share no synchronisation, so their tile-traffic and matrix phases drift apart and interleave on each SIMD.
-template <int kNCH = 2, int kAbl = 0, int kW = 8>
+// kLd0: the group of the item's first tile LOAD (the stores of the previous item's results start at group 0, one per group).  0: a piece's
+// register gives up its result and takes the new tile value in the same group (k_flush_strip32's scheme): 5.24 ms at 40 000 landmarks; 2 / 3 /
+// 4 / 5 / 8: 4.99 / 4.94 / 4.95 / 4.99 / 5.05 (round4_tuning.md 56) -- the loads a few groups BEHIND the stores, closer to the epilogue that
+// needs them and to the store that follows.  (kNCH = 1: the loads cannot leave the item's only chunk.)
+template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0)>
 __global__ __launch_bounds__(64 * kW)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                     const uint16_t *__restrict__ Kb, const uint16_t *__restrict__ Gb, int64_t ldm, TileMap tm, float *__restrict__ dump) {
     constexpr int T = 256, NG = 8 * kNCH, NKBU = 2 * kNCH;                 // groups (k-block, column block) and k-blocks per item
     static_assert(kNCH == 1 || kNCH == 2, "chunks per item");
     static_assert(kW == 8 || kW == 4, "wavefronts per workgroup");
+    static_assert(kLd0 >= 0 && kLd0 + 8 <= 8 * kNCH, "the eight tile loads of an item sit in groups kLd0 .. kLd0 + 7");
     constexpr int kCG = kW / 4;                                            // 64-column groups per item
     constexpr uint32_t kChunk = 2 * 3 * kCG * 4096;                        // G of one chunk in LDS: [kbl 2][plane 3][column group kCG][e 4][1 KiB]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -193,10 +199,10 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         const uint32_t fm = flip ? 0x80008000u : 0u;
         *reinterpret_cast<u4_t *>(smem + (uint32_t)buf * kChunk + (uint32_t)(wave + kW * j) * 1024 + (uint32_t)lane * 16) = gq[j] ^ u4_t{ fm, fm, fm, fm };
     };
-    // Tile traffic as in k_flush_strip32: ONE register buffer of eight 16-byte pieces carries two items at a time -- in the item's first
-    // chunk each piece's register first gives up the PREVIOUS item's finished entries (a store), then takes the CURRENT item's tile value (a
-    // load); at the item's end the accumulators are added into it.  (Requesting the NEXT item's pieces at the epilogue instead -- eight stores
-    // and eight loads in one burst per wavefront, all eight wavefronts at once -- measured slower: 5.8 against 5.2 ms, round4_tuning.md 53.)
+    // Tile traffic: ONE register buffer of eight 16-byte pieces carries two items at a time -- piece p's register gives up the PREVIOUS item's
+    // finished entries in group p (a store) and takes the CURRENT item's tile value in group kLd0 + p (a load); at the item's end the
+    // accumulators are added into it.  (Requesting the NEXT item's pieces at the epilogue instead -- eight stores and eight loads in one burst
+    // per wavefront, all eight wavefronts at once -- measured slower: 5.8 against 5.2 ms, round4_tuning.md 53.)
     f4_t acc[2][4], tl[8];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -273,18 +279,20 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 sub_mark(6, tg0);
             }
             mfma_group(2 * ch + (gl >> 2), gl & 3, fb[gi & 1]);
-            if ((kAbl & 32) ? gi < 4 : gi < 8) {
+            if ((kAbl & (32 | 512)) ? gi < 4 : gi < 8) {
                 const unsigned long long tt0 = sub_start();
                 // the tile pieces: the register first gives up the PREVIOUS item's finished entries, then takes this item's tile value
 #pragma unroll
-                for (int p = (kAbl & 32) ? 2 * gi : gi; p < ((kAbl & 32) ? 2 * gi + 2 : gi + 1); ++p) {
+                for (int p = (kAbl & (32 | 512)) ? 2 * gi : gi; p < ((kAbl & (32 | 512)) ? 2 * gi + 2 : gi + 1); ++p) {
                     f4_t *po = reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p));
                     const f4_t *pi = reinterpret_cast<const f4_t *>(in_base + piece_off(p));
-                    if (!(kAbl & 1)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
-                    if (!(kAbl & 2)) { if (kAbl & 16) tl[p] = *pi; else tl[p] = __builtin_nontemporal_load(pi); }
+                    if (!(kAbl & 1) && !(kAbl & 2048)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
+                    if (!(kAbl & 2) && kLd0 == 0) { if (kAbl & 16) tl[p] = *pi; else tl[p] = __builtin_nontemporal_load(pi); }
                 }
                 sub_mark(7, tt0);
             }
+            if (kLd0 > 0 && gi >= kLd0 && gi < kLd0 + 8 && !(kAbl & 2))     // the tile loads, kLd0 groups behind the stores
+                tl[gi - kLd0] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(gi - kLd0)));
             __builtin_amdgcn_sched_barrier(0);
             if (gl == 7 && gi + 1 < NG) {
                 // WAIT between the chunks of an item
@@ -305,6 +313,10 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             for (int e = 0; e < 4; ++e) tl[p][e] = fmaf(acc[p >> 2][e][p & 3], sgn, tl[p][e]);     // (exact product: one rounding, as tl + acc)
         zero_acc();
         out_base = reinterpret_cast<const char *>(dst + cur.toff);
+        if constexpr ((kAbl & 2048) != 0) {                                // (probe variant 2048: the results leave at once, in one burst)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
+        }
         mark(3);
         seg[5] += 1;
         if (nxt.krow0 < 0) break;
@@ -317,9 +329,11 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         read_frags(buf, 0, fb[0]);
         mark(4);
     }
+    if constexpr ((kAbl & 2048) == 0) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p)                                            // the last item's result
-        __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
+        for (int p = 0; p < 8; ++p)                                        // the last item's result
+            __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
+    }
     if constexpr ((kAbl & 64) != 0) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(dump + (size_t)blockIdx.x * (kItem * T)) + wave * 8;
         if (lane == 0)

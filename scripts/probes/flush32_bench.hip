@@ -228,6 +228,14 @@ int main(int argc, char **argv) {
         { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> , 8 },
         { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> , 8 },
         { "  var: the younger wavefronts' G block four groups later", ekf_pipe32::k_flush_split3<2, 256> , 8 },
+        { "  var: tile loads from group 0 (beside the stores)", ekf_pipe32::k_flush_split3<2, 0, 8, 0> , 8 },
+        { "  var: tile loads from group 2", ekf_pipe32::k_flush_split3<2, 0, 8, 2> , 8 },
+        { "  var: tile loads from group 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3> , 8 },
+        { "  var: tile loads from group 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5> , 8 },
+        { "  var: tile loads from group 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8> , 8 },
+        { "  var: stores two per group in 0-3, loads from group 4", ekf_pipe32::k_flush_split3<2, 512, 8, 4> , 8 },
+        { "  var: stores two per group in 0-3, loads from group 3", ekf_pipe32::k_flush_split3<2, 512, 8, 3> , 8 },
+        { "  var: tile loads from group 4, results stored at the epilogue", ekf_pipe32::k_flush_split3<2, 2048, 8, 4> , 8 },
     };
     const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 2;
     for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split(vp[v].waves)));
