@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // register gives up its result and takes the new tile value in the same group (k_flush_strip32's scheme): 5.24 ms at 40 000 landmarks; 2 / 3 /
 // 4 / 5 / 8: 4.99 / 4.94 / 4.95 / 4.99 / 5.05 (round4_tuning.md 56) -- the loads a few groups BEHIND the stores, closer to the epilogue that
 // needs them and to the store that follows.  (kNCH = 1: the loads cannot leave the item's only chunk.)
-template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0)>
+template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0), int kSt0 = 0>
 __global__ __launch_bounds__(64 * kW)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                     const uint16_t *__restrict__ Kb, const uint16_t *__restrict__ Gb, int64_t ldm, TileMap tm, float *__restrict__ dump) {
@@ -114,6 +114,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     static_assert(kNCH == 1 || kNCH == 2, "chunks per item");
     static_assert(kW == 8 || kW == 4, "wavefronts per workgroup");
     static_assert(kLd0 >= 0 && kLd0 + 8 <= 8 * kNCH, "the eight tile loads of an item sit in groups kLd0 .. kLd0 + 7");
+    static_assert(kSt0 >= 0 && kSt0 <= kLd0 && (kSt0 == 0 || kLd0 > 0), "the stores of the previous item's results sit in groups kSt0 .. kSt0 + 7, not behind the loads");
     constexpr int kCG = kW / 4;                                            // 64-column groups per item
     constexpr uint32_t kChunk = 2 * 3 * kCG * 4096;                        // G of one chunk in LDS: [kbl 2][plane 3][column group kCG][e 4][1 KiB]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -279,11 +280,11 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 sub_mark(6, tg0);
             }
             mfma_group(2 * ch + (gl >> 2), gl & 3, fb[gi & 1]);
-            if ((kAbl & (32 | 512)) ? gi < 4 : gi < 8) {
+            if ((kAbl & (32 | 512)) ? gi < 4 : (gi >= kSt0 && gi < kSt0 + 8)) {
                 const unsigned long long tt0 = sub_start();
                 // the tile pieces: the register first gives up the PREVIOUS item's finished entries, then takes this item's tile value
 #pragma unroll
-                for (int p = (kAbl & (32 | 512)) ? 2 * gi : gi; p < ((kAbl & (32 | 512)) ? 2 * gi + 2 : gi + 1); ++p) {
+                for (int p = (kAbl & (32 | 512)) ? 2 * gi : gi - kSt0; p < ((kAbl & (32 | 512)) ? 2 * gi + 2 : gi - kSt0 + 1); ++p) {
                     f4_t *po = reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p));
                     const f4_t *pi = reinterpret_cast<const f4_t *>(in_base + piece_off(p));
                     if (!(kAbl & 1) && !(kAbl & 2048)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }

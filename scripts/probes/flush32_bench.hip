@@ -233,6 +233,11 @@ int main(int argc, char **argv) {
         { "  var: tile loads from group 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3> , 8 },
         { "  var: tile loads from group 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5> , 8 },
         { "  var: tile loads from group 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8> , 8 },
+        { "  var: stores from group 1, loads from 4", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 1> , 8 },
+        { "  var: stores from group 2, loads from 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5, 2> , 8 },
+        { "  var: stores from group 2, loads from 6", ekf_pipe32::k_flush_split3<2, 0, 8, 6, 2> , 8 },
+        { "  var: stores from group 4, loads from 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8, 4> , 8 },
+        { "  var: stores from group 1, loads from 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3, 1> , 8 },
         { "  var: stores two per group in 0-3, loads from group 4", ekf_pipe32::k_flush_split3<2, 512, 8, 4> , 8 },
         { "  var: stores two per group in 0-3, loads from group 3", ekf_pipe32::k_flush_split3<2, 512, 8, 3> , 8 },
         { "  var: tile loads from group 4, results stored at the epilogue", ekf_pipe32::k_flush_split3<2, 2048, 8, 4> , 8 },
