@@ -67,7 +67,8 @@ inline int4 strip_entry(const TileMap &tm, int I, int J, int slab, int cpart) {
 }
 
 // kS: stages of eight pairs per item = ceil(npairs / 8) (a template parameter: the k-step loop is unrolled, see the tile traffic below)
-template <int kS = 8, bool kStamp = false>
+// kLd: the k-step of the item's first tile LOAD (piece p's load at k-step kLd + 2 p; its store -- the previous item's result -- stays at k-step 2 p)
+template <int kS = 8, bool kStamp = false, int kLd = 0>
 __global__ __launch_bounds__(512)
 void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                      const float *__restrict__ Kn, const float *__restrict__ G, int64_t pair_stride, int64_t ldm, int pstart, int pcap,
@@ -204,6 +205,7 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
     constexpr int kG0 = kBar - 2 * (GQ - 1);                                         // the G pieces move at k-steps kG0, kG0 + 2, ... <= kBar: the tile pieces own the first half
     static_assert(kG0 >= 0 && kG0 + 2 * (GQ - 1) <= kBar, "the G pieces are in LDS before the item's barrier");
     static_assert(NK % 4 == 0, "k-steps per item");
+    static_assert(kLd >= 0 && kLd % 2 == 0 && kLd + 16 <= NK, "the tile loads end before the item does");
 
     // prologue: the first item's G straight into buffer 0, the second's into the registers
 #pragma unroll
@@ -239,8 +241,10 @@ void k_flush_strip32(const float *__restrict__ tiles, float *__restrict__ dst, c
                 // conditional store hipcc loads into a temporary, waits for it at once and copies)
                 const int p = g / 2;
                 __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
-                tl[p] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(p)));
+                if (kLd == 0) tl[p] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off(p)));
             }
+            if (kLd > 0 && g >= kLd && g < kLd + 16 && (g - kLd) % 2 == 0)
+                tl[(g - kLd) / 2] = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(in_base + piece_off((g - kLd) / 2)));
             if (g >= kG0 && (g - kG0) % 2 == 0 && (g - kG0) / 2 < GQ) {     // the next item's G into the buffer the last barrier freed; the one after it on its way
                 write_g(buf ^ 1, (g - kG0) / 2);
                 load_g(nn, (g - kG0) / 2);

@@ -197,6 +197,10 @@ int main(int argc, char **argv) {
     struct VarS { const char *name; fns_t fn; int lds, threads, D; };
     const VarS vs[] = {
         { "k_flush_strip32<8>", ekf_pipe32::k_flush_strip32<8>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
+        { "k_flush_strip32<8,.,4> (tile loads from k-step 4)", ekf_pipe32::k_flush_strip32<8, false, 4>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
+        { "k_flush_strip32<8,.,8>", ekf_pipe32::k_flush_strip32<8, false, 8>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
+        { "k_flush_strip32<8,.,12>", ekf_pipe32::k_flush_strip32<8, false, 12>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
+        { "k_flush_strip32<8,.,16>", ekf_pipe32::k_flush_strip32<8, false, 16>, ekf_pipe32::lds_bytes_strip<8>(), 512, 2 },
     };
     constexpr int nvs = sizeof(vs) / sizeof(vs[0]);
     for (int v = 0; v < nvs; ++v) CHK(hipFuncSetAttribute((const void *)vs[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, vs[v].lds));
