@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // register gives up its result and takes the new tile value in the same group (k_flush_strip32's scheme): 5.24 ms at 40 000 landmarks; 2 / 3 /
 // 4 / 5 / 8: 4.99 / 4.94 / 4.95 / 4.99 / 5.05 (round4_tuning.md 56) -- the loads a few groups BEHIND the stores, closer to the epilogue that
 // needs them and to the store that follows.  (kNCH = 1: the loads cannot leave the item's only chunk.)
-template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0), int kSt0 = 0>
+template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0), int kSt0 = 0, int kGb = 0>
 __global__ __launch_bounds__(64 * kW)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                     const uint16_t *__restrict__ Kb, const uint16_t *__restrict__ Gb, int64_t ldm, TileMap tm, float *__restrict__ dump) {
@@ -114,6 +114,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     static_assert(kNCH == 1 || kNCH == 2, "chunks per item");
     static_assert(kW == 8 || kW == 4, "wavefronts per workgroup");
     static_assert(kLd0 >= 0 && kLd0 + 8 <= 8 * kNCH, "the eight tile loads of an item sit in groups kLd0 .. kLd0 + 7");
+    static_assert(kGb >= 0 && kGb <= 6, "the G block of a chunk sits in front of the chunk's ARRIVE (group 7)");
     static_assert(kSt0 >= 0 && kSt0 <= kLd0 && (kSt0 == 0 || kLd0 > 0), "the stores of the previous item's results sit in groups kSt0 .. kSt0 + 7, not behind the loads");
     constexpr int kCG = kW / 4;                                            // 64-column groups per item
     constexpr uint32_t kChunk = 2 * 3 * kCG * 4096;                        // G of one chunk in LDS: [kbl 2][plane 3][column group kCG][e 4][1 KiB]
@@ -262,7 +263,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if ((kAbl & 256) ? ((gl == 0 && wave < kW / 2) || (gl == 4 && wave >= kW / 2)) : gl == 0) {     // (probe variant 256: the younger wavefronts' G block four groups later)
+            if ((kAbl & 256) ? ((gl == 0 && wave < kW / 2) || (gl == 4 && wave >= kW / 2)) : gl == kGb) {     // (probe variant 256: the younger wavefronts' G block four groups later)
                 // The next chunk's G into the buffer the last WAIT freed, the chunk after it on its way: all six pieces here, in front of the chunk's
                 // tile traffic.  (Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load and store;
                 // here the G pieces waited for are older than every tile piece in flight.  Spread over the chunk between the tile pieces --

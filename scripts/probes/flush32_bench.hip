@@ -237,6 +237,9 @@ int main(int argc, char **argv) {
         { "  var: tile loads from group 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3> , 8 },
         { "  var: tile loads from group 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5> , 8 },
         { "  var: tile loads from group 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8> , 8 },
+        { "  var: G block in group 2", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 2> , 8 },
+        { "  var: G block in group 4", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 4> , 8 },
+        { "  var: G block in group 6", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 6> , 8 },
         { "  var: stores from group 1, loads from 4", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 1> , 8 },
         { "  var: stores from group 2, loads from 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5, 2> , 8 },
         { "  var: stores from group 2, loads from 6", ekf_pipe32::k_flush_split3<2, 0, 8, 6, 2> , 8 },
