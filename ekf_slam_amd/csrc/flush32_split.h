@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
 // tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps, 256 the younger wavefronts' G block four
 // groups later, 512 the tile STORES two per group in the item's first quarter (with kLd0 > 0), 2048 the results stored in one burst at the
-// epilogue -- never the product kernel
+// epilogue, 4096 a tile layout in which an item is one contiguous block (timing only) -- never the product kernel
 // kW: wavefronts per workgroup.  8: one workgroup per CU, an item = a work-list entry (128 x 128).  4: TWO independent workgroups per CU (the
 // same two wavefronts per SIMD), an item = a 64-column half of an entry (both halves by the same workgroup, one after the other: -K stays):
 // the two workgroups of a CU share no synchronisation, so their tile-traffic and matrix phases drift apart and interleave on each SIMD.
@@ -165,7 +165,10 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     // (lr, lc): A = -K(row 32 wi + 16 rb + lc, k 8 lr ..) in ka[rb][kb][p]; B = G(k 8 lr .., column 64 wj + 4 lc + e); accumulators acc[rb][e][i] =
     // entry (row 32 wi + 16 rb + 4 lr + i, column 64 wj + 4 lc + e): the lane's tile piece 4 rb + i is sixteen consecutive bytes of that row
     const int wi = kW == 8 ? wave >> 1 : wave, wj = kW == 8 ? wave & 1 : 0;
-    const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * T + 64 * wj + 4 * lc) * 4;
+    // (probe variant 4096: the item's rows 128 floats apart -- a layout experiment in which a 128 x 128 item is ONE contiguous 64 KiB block of its
+    // tile; the work list then carries that layout's offsets and the result is only a timing)
+    constexpr int kRS = (kAbl & 4096) ? 128 : T;                          // floats between two rows of an item
+    const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * kRS + 64 * wj + 4 * lc) * 4;
     bf8_t ka[2][NKBU][3];
     auto load_k = [&](const StripItem &q) {
         uint32_t kl = (uint32_t)((32 * wi + lc) * 64 + lr * 16);
@@ -212,7 +215,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[rb][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
     };
-    auto piece_off = [&](int p) { return (size_t)(((p >> 2) * 16 + (p & 3)) * T) * 4 + t_lane; };
+    auto piece_off = [&](int p) { return (size_t)(((p >> 2) * 16 + (p & 3)) * kRS) * 4 + t_lane; };
     const char *out_base = reinterpret_cast<const char *>(dump + (size_t)blockIdx.x * (kItem * T)), *in_base = nullptr;     // dump: 128 KiB per workgroup
 #pragma unroll
     for (int p = 0; p < 8; ++p) tl[p] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
