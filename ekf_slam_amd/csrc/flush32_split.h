@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // One work-list entry = a 128 x 128 item (flush32_pipe.h: strip_entry, the segments of build_strip_segments); an item = kNCH chunks of two
 // k-blocks.  kNCH = 2: up to 64 pairs; kNCH = 1: up to 32 (the planes of k-blocks 2, 3 are not touched).
 // kAbl (probe builds only, scripts/probes/flush32_bench.hip): 1 no tile stores, 2 no tile loads, 4 no G loads; 8 / 16 plain instead of nontemporal
-// tile stores / loads, 32 the tile pieces two per group in the item's first quarter, 64 s_memtime stamps, 256 the younger wavefronts' G block four
-// groups later, 512 the tile STORES two per group in the item's first quarter (with kLd0 > 0), 2048 the results stored in one burst at the
-// epilogue, 4096 a tile layout in which an item is one contiguous block (timing only) -- never the product kernel
+// tile stores / loads; 64 s_memtime stamps -- never the product kernel.  (The schedule variants that were measured and lost -- the tile pieces two per
+// group, the G block elsewhere in the chunk or staggered between a SIMD's wavefronts, later stores, results stored in one burst, a contiguous-item
+// tile layout -- are in profiles/round4_tuning.md 53-56, not here.)
 // kW: wavefronts per workgroup.  8: one workgroup per CU, an item = a work-list entry (128 x 128).  4: TWO independent workgroups per CU (the
 // same two wavefronts per SIMD), an item = a 64-column half of an entry (both halves by the same workgroup, one after the other: -K stays):
 // the two workgroups of a CU share no synchronisation, so their tile-traffic and matrix phases drift apart and interleave on each SIMD.
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_split_pairs(const float *__restrict__ K
 // register gives up its result and takes the new tile value in the same group (k_flush_strip32's scheme): 5.24 ms at 40 000 landmarks; 2 / 3 /
 // 4 / 5 / 8: 4.99 / 4.94 / 4.95 / 4.99 / 5.05 (round4_tuning.md 56) -- the loads a few groups BEHIND the stores, closer to the epilogue that
 // needs them and to the store that follows.  (kNCH = 1: the loads cannot leave the item's only chunk.)
-template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0), int kSt0 = 0, int kGb = 0>
+template <int kNCH = 2, int kAbl = 0, int kW = 8, int kLd0 = (kNCH == 2 ? 4 : 0)>
 __global__ __launch_bounds__(64 * kW)
 void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, const int4 *__restrict__ segs, int64_t nsegs,
                     const uint16_t *__restrict__ Kb, const uint16_t *__restrict__ Gb, int64_t ldm, TileMap tm, float *__restrict__ dump) {
@@ -114,8 +114,6 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     static_assert(kNCH == 1 || kNCH == 2, "chunks per item");
     static_assert(kW == 8 || kW == 4, "wavefronts per workgroup");
     static_assert(kLd0 >= 0 && kLd0 + 8 <= 8 * kNCH, "the eight tile loads of an item sit in groups kLd0 .. kLd0 + 7");
-    static_assert(kGb >= 0 && kGb <= 6, "the G block of a chunk sits in front of the chunk's ARRIVE (group 7)");
-    static_assert(kSt0 >= 0 && kSt0 <= kLd0 && (kSt0 == 0 || kLd0 > 0), "the stores of the previous item's results sit in groups kSt0 .. kSt0 + 7, not behind the loads");
     constexpr int kCG = kW / 4;                                            // 64-column groups per item
     constexpr uint32_t kChunk = 2 * 3 * kCG * 4096;                        // G of one chunk in LDS: [kbl 2][plane 3][column group kCG][e 4][1 KiB]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,10 +163,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
     // (lr, lc): A = -K(row 32 wi + 16 rb + lc, k 8 lr ..) in ka[rb][kb][p]; B = G(k 8 lr .., column 64 wj + 4 lc + e); accumulators acc[rb][e][i] =
     // entry (row 32 wi + 16 rb + 4 lr + i, column 64 wj + 4 lc + e): the lane's tile piece 4 rb + i is sixteen consecutive bytes of that row
     const int wi = kW == 8 ? wave >> 1 : wave, wj = kW == 8 ? wave & 1 : 0;
-    // (probe variant 4096: the item's rows 128 floats apart -- a layout experiment in which a 128 x 128 item is ONE contiguous 64 KiB block of its
-    // tile; the work list then carries that layout's offsets and the result is only a timing)
-    constexpr int kRS = (kAbl & 4096) ? 128 : T;                          // floats between two rows of an item
-    const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * kRS + 64 * wj + 4 * lc) * 4;
+    const uint32_t t_lane = (uint32_t)((32 * wi + 4 * lr) * T + 64 * wj + 4 * lc) * 4;
     bf8_t ka[2][NKBU][3];
     auto load_k = [&](const StripItem &q) {
         uint32_t kl = (uint32_t)((32 * wi + lc) * 64 + lr * 16);
@@ -215,7 +210,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[rb][e] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
     };
-    auto piece_off = [&](int p) { return (size_t)(((p >> 2) * 16 + (p & 3)) * kRS) * 4 + t_lane; };
+    auto piece_off = [&](int p) { return (size_t)(((p >> 2) * 16 + (p & 3)) * T) * 4 + t_lane; };
     const char *out_base = reinterpret_cast<const char *>(dump + (size_t)blockIdx.x * (kItem * T)), *in_base = nullptr;     // dump: 128 KiB per workgroup
 #pragma unroll
     for (int p = 0; p < 8; ++p) tl[p] = f4_t{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -266,7 +261,7 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(&arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if ((kAbl & 256) ? ((gl == 0 && wave < kW / 2) || (gl == 4 && wave >= kW / 2)) : gl == kGb) {     // (probe variant 256: the younger wavefronts' G block four groups later)
+            if (gl == 0) {
                 // The next chunk's G into the buffer the last WAIT freed, the chunk after it on its way: all six pieces here, in front of the chunk's
                 // tile traffic.  (Vector-memory operations retire in issue order, so a wait for a G piece also waits for every older load and store;
                 // here the G pieces waited for are older than every tile piece in flight.  Spread over the chunk between the tile pieces --
@@ -284,14 +279,14 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
                 sub_mark(6, tg0);
             }
             mfma_group(2 * ch + (gl >> 2), gl & 3, fb[gi & 1]);
-            if ((kAbl & (32 | 512)) ? gi < 4 : (gi >= kSt0 && gi < kSt0 + 8)) {
+            if (gi < 8) {
                 const unsigned long long tt0 = sub_start();
                 // the tile pieces: the register first gives up the PREVIOUS item's finished entries, then takes this item's tile value
-#pragma unroll
-                for (int p = (kAbl & (32 | 512)) ? 2 * gi : gi - kSt0; p < ((kAbl & (32 | 512)) ? 2 * gi + 2 : gi - kSt0 + 1); ++p) {
+                {
+                    const int p = gi;
                     f4_t *po = reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p));
                     const f4_t *pi = reinterpret_cast<const f4_t *>(in_base + piece_off(p));
-                    if (!(kAbl & 1) && !(kAbl & 2048)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
+                    if (!(kAbl & 1)) { if (kAbl & 8) *po = tl[p]; else __builtin_nontemporal_store(tl[p], po); }
                     if (!(kAbl & 2) && kLd0 == 0) { if (kAbl & 16) tl[p] = *pi; else tl[p] = __builtin_nontemporal_load(pi); }
                 }
                 sub_mark(7, tt0);
@@ -318,10 +313,6 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
             for (int e = 0; e < 4; ++e) tl[p][e] = fmaf(acc[p >> 2][e][p & 3], sgn, tl[p][e]);     // (exact product: one rounding, as tl + acc)
         zero_acc();
         out_base = reinterpret_cast<const char *>(dst + cur.toff);
-        if constexpr ((kAbl & 2048) != 0) {                                // (probe variant 2048: the results leave at once, in one burst)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
-        }
         mark(3);
         seg[5] += 1;
         if (nxt.krow0 < 0) break;
@@ -334,11 +325,9 @@ void k_flush_split3(const float *__restrict__ tiles, float *__restrict__ dst, co
         read_frags(buf, 0, fb[0]);
         mark(4);
     }
-    if constexpr ((kAbl & 2048) == 0) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p)                                        // the last item's result
-            __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
-    }
+    for (int p = 0; p < 8; ++p)                                            // the last item's result
+        __builtin_nontemporal_store(tl[p], reinterpret_cast<f4_t *>(const_cast<char *>(out_base) + piece_off(p)));
     if constexpr ((kAbl & 64) != 0) {
         unsigned long long *st = reinterpret_cast<unsigned long long *>(dump + (size_t)blockIdx.x * (kItem * T)) + wave * 8;
         if (lane == 0)

@@ -174,19 +174,6 @@ int main(int argc, char **argv) {
     int4 *d_segs = nullptr;
     CHK(hipMalloc(&d_segs, segflat.size() * sizeof(int4)));
     CHK(hipMemcpy(d_segs, segflat.data(), segflat.size() * sizeof(int4), hipMemcpyHostToDevice));
-    // SUBLAYOUT experiment (timing only): the same segments with the offsets of a layout in which each 128 x 128 item of a tile is contiguous
-    int4 *d_segs_sub = nullptr;
-    {
-        std::vector<int4> sub(segflat);
-        for (int4 &e : sub) {
-            if (e.z < 0) continue;
-            const int I = e.z / 256, slab = (e.z % 256) / 128, J = e.w / 256, cpart = (e.w % 256) / 128;
-            const int64_t toff = tm.tile_offset(I, J) + (int64_t)(slab * 2 + cpart) * (128 * 128);
-            e.x = (int)(uint32_t)(toff & 0xffffffffll); e.y = (int)(uint32_t)((uint64_t)toff >> 32);
-        }
-        CHK(hipMalloc(&d_segs_sub, sub.size() * sizeof(int4)));
-        CHK(hipMemcpy(d_segs_sub, sub.data(), sub.size() * sizeof(int4), hipMemcpyHostToDevice));
-    }
     const int64_t telems = (int64_t)tot * T * T, pair_stride = 2 * ldm;
     float *tiles, *out_a = nullptr, *out_b = nullptr, *Kil, *Gil, *Kn, *Gpl;
     CHK(hipMalloc(&tiles, telems * 4));
@@ -228,7 +215,7 @@ int main(int argc, char **argv) {
     CHK(hipMemset(Kb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2)); CHK(hipMemset(Gb3, 0, ekf_pipe32::split_plane_elems(ldm) * 2));
     typedef void (*fsp_t)(const float *, float *, const int4 *, int64_t, const uint16_t *, const uint16_t *, int64_t, TileMap, float *);
     // ABL=1: the ablations beside the kernel (diagnostic instances: results are wrong by construction)
-    struct VarP { const char *name; fsp_t fn; int waves; bool sub = false; };
+    struct VarP { const char *name; fsp_t fn; int waves; };
     const VarP vp[] = {
         { "k_flush_split3<2>", ekf_pipe32::k_flush_split3<2, 0>, 8 },
         { "k_flush_split3<2,0,4>: two workgroups of four wavefronts per CU", ekf_pipe32::k_flush_split3<2, 0, 4>, 4 },
@@ -243,32 +230,18 @@ int main(int argc, char **argv) {
         { "  var: plain tile stores", ekf_pipe32::k_flush_split3<2, 8> , 8 },
         { "  var: plain tile loads", ekf_pipe32::k_flush_split3<2, 16> , 8 },
         { "  var: plain stores and loads", ekf_pipe32::k_flush_split3<2, 24> , 8 },
-        { "  var: tile pieces in the first quarter", ekf_pipe32::k_flush_split3<2, 32> , 8 },
-        { "  var: the younger wavefronts' G block four groups later", ekf_pipe32::k_flush_split3<2, 256> , 8 },
         { "  var: tile loads from group 0 (beside the stores)", ekf_pipe32::k_flush_split3<2, 0, 8, 0> , 8 },
         { "  var: tile loads from group 2", ekf_pipe32::k_flush_split3<2, 0, 8, 2> , 8 },
         { "  var: tile loads from group 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3> , 8 },
         { "  var: tile loads from group 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5> , 8 },
         { "  var: tile loads from group 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8> , 8 },
-        { "  layout experiment: every 128 x 128 item one contiguous 64 KiB block (timing only)", ekf_pipe32::k_flush_split3<2, 4096> , 8, true },
-        { "  var: G block in group 2", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 2> , 8 },
-        { "  var: G block in group 4", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 4> , 8 },
-        { "  var: G block in group 6", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 0, 6> , 8 },
-        { "  var: stores from group 1, loads from 4", ekf_pipe32::k_flush_split3<2, 0, 8, 4, 1> , 8 },
-        { "  var: stores from group 2, loads from 5", ekf_pipe32::k_flush_split3<2, 0, 8, 5, 2> , 8 },
-        { "  var: stores from group 2, loads from 6", ekf_pipe32::k_flush_split3<2, 0, 8, 6, 2> , 8 },
-        { "  var: stores from group 4, loads from 8", ekf_pipe32::k_flush_split3<2, 0, 8, 8, 4> , 8 },
-        { "  var: stores from group 1, loads from 3", ekf_pipe32::k_flush_split3<2, 0, 8, 3, 1> , 8 },
-        { "  var: stores two per group in 0-3, loads from group 4", ekf_pipe32::k_flush_split3<2, 512, 8, 4> , 8 },
-        { "  var: stores two per group in 0-3, loads from group 3", ekf_pipe32::k_flush_split3<2, 512, 8, 3> , 8 },
-        { "  var: tile loads from group 4, results stored at the epilogue", ekf_pipe32::k_flush_split3<2, 2048, 8, 4> , 8 },
     };
     const int nvp = (getenv("ABL") && atoi(getenv("ABL"))) ? (int)(sizeof(vp) / sizeof(vp[0])) : 2;
     for (int v = 0; v < nvp; ++v) CHK(hipFuncSetAttribute((const void *)vp[v].fn, hipFuncAttributeMaxDynamicSharedMemorySize, ekf_pipe32::lds_bytes_split(vp[v].waves)));
     auto launch_split = [&](float *dstp, bool cut, int v = 0) {
         if (cut) hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(ldm / 256), ekf_pipe32::kKB, 2), dim3(256), 0, 0, (const float *)Kn, (const float *)Gpl, Kb3, Gb3,
                                     pair_stride, ldm, ldm, pstart, pcap, npairs);
-        hipLaunchKernelGGL(vp[v].fn, dim3(grid * 8 / vp[v].waves), dim3(64 * vp[v].waves), ekf_pipe32::lds_bytes_split(vp[v].waves), 0, (const float *)tiles, dstp, vp[v].sub ? d_segs_sub : d_segs, nsegs,
+        hipLaunchKernelGGL(vp[v].fn, dim3(grid * 8 / vp[v].waves), dim3(64 * vp[v].waves), ekf_pipe32::lds_bytes_split(vp[v].waves), 0, (const float *)tiles, dstp, d_segs, nsegs,
                            (const uint16_t *)Kb3, (const uint16_t *)Gb3, ldm, tm, dump);
     };
     auto strip_ok = [&](int v) { return (npairs + 7) / 8 == 8; };      // (instantiated for eight stages: 57-64 pairs)
