@@ -198,6 +198,7 @@ def test_device_loop_mismatch_is_reported_once_at_the_next_synchronising_call(ki
         # the host's mirror finds no landmark for signature 500 and queues an append; on the device landmark 3 carries that signature
         assert e.lib.ekf_diag_poke_device_signature(e.h, 2, 500.0) == L.EKF_OK
         rows = [[12.0, 30.0, 500.0]]
+    assert e.lib.ekf_diag_poke_device_signature(e.h, N, 1.0) == L.EKF_ERR_INVALID_ARG      # no such landmark: refused, nothing written
     e.predict(u)
     e.measure(rows, u, idx, loc)                                              # EKF_OK: nothing is waited for
     with pytest.raises(EkfError) as ei:
