@@ -1212,7 +1212,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         HIPCHK(h, dalloc(h, &dump, (size_t)h->aux.grid * ekf_pipe32::kDumpFloats));
         h->aux.dump = dump;
         if (cfg->pass_arith == EKF_ARITH_SPLIT3) {
-            // the bf16 planes of the pending pairs (flush32_split.h), cut from the float copies in front of every pass of 33-64 pairs
+            // the bf16 planes of the pending pairs (flush32_split.h), cut from the float copies in front of every pass of 28-64 pairs
             HIPCHK(h, dalloc(h, &h->aux.Kb3, pass_split_plane_elems(ldm)));
             HIPCHK(h, dalloc(h, &h->aux.Gb3, pass_split_plane_elems(ldm)));
         }

@@ -229,8 +229,9 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
         if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
         if constexpr (sizeof(TS) == 4) {
             static const bool use_strip = ekf_tune_int("EKF_PASS_STRIP", 1) != 0;
-            if (arith == 2 && npairs > 32 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0 && aux->Kb3 && aux->Gb3) {
-                // cfg.pass_arith = EKF_ARITH_SPLIT3, 33-64 pairs: the float copies cut into three bf16 planes (logical pair order, zeros beyond
+            if (arith == 2 && npairs >= 28 && npairs <= 64 && aux && aux->segs && aux->nsegs > 0 && aux->Kb3 && aux->Gb3) {
+                // cfg.pass_arith = EKF_ARITH_SPLIT3, 28-64 pairs (below, the F32 kernels are the faster ones: 20 pairs 4.27 against 4.75 ms at 40 000 landmarks, 32
+                // pairs 5.08 against 4.74 -- round4_tuning.md 57): the float copies cut into three bf16 planes (logical pair order, zeros beyond
                 // npairs), then the strip form of the pass on the bf16 matrix pipe (flush32_split.h) -- bound by HBM, not by the matrix pipe
                 static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_split3<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                    ekf_pipe32::lds_bytes_split());
@@ -258,7 +259,7 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                     return true;
                 }
             }
-            if (arith >= 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32 (and EKF_ARITH_SPLIT3 up to 32 pairs): the f32 matrix pipe (one or two pairs: the pass is
+            if (arith >= 1 && npairs > 2) {                           // cfg.pass_arith = EKF_ARITH_F32 (and EKF_ARITH_SPLIT3 up to 27 pairs): the f32 matrix pipe (one or two pairs: the pass is
                                                                       // purely HBM-bound and the F64-arithmetic kernel below streams it 5 % faster, 4.0 against 4.3 ms at 40 k)
 #define EKF_M32(CH, RG, WPE) do { int64_t g32 = 8 * xcd_len * (T / (64 * RG)) * (T / 128); if (grid_cap > 0 && g32 > grid_cap) g32 = grid_cap; \
                                   hipLaunchKernelGGL((k_flush_mfma32<T, CH, RG, WPE>), dim3((unsigned)g32), dim3(kBlock), 0, s, (const float *)st.tiles, \

@@ -125,8 +125,9 @@ typedef struct ekf_config {
                                     products that matter (what is dropped is at most 2^-23 of it, 0.09 x 2^-24 in the root mean square),
                                     each exact in float, summed in float on the bf16 matrix pipe from zero, then added to the tile
                                     value once.  Same error class as EKF_ARITH_F32 (a float sum of 2m terms; measured against an F64
-                                    sum beside the fmaf chain: DESIGN.md section 5), NOT the same bits; at 33-64 pending pairs the
-                                    pass is then bound by HBM instead of the f32 matrix pipe.  Up to 32 pairs: EKF_ARITH_F32's kernels.
+                                    sum beside the fmaf chain: DESIGN.md section 5), NOT the same bits; at 28-64 pending pairs the
+                                    pass is then bound by HBM instead of the f32 matrix pipe.  Up to 27 pairs: EKF_ARITH_F32's kernels
+                                    (faster there).
                                     Costs 2 x 768 bytes per row of P for the planes. */
     int32_t reserved[2];
 } ekf_config;

@@ -42,7 +42,7 @@ def bound_x(k, storage="f32"):
 
 # (P: offset, per update-step; x: offset, per update-step).  "f32_mixed" = cfg.pass_arith = EKF_ARITH_F32: the pass over P on the f32
 # matrix pipe, K and G rounded to float, one float rounding per rank-1 term (module docstring, last paragraph)
-# "f32_split" = EKF_ARITH_SPLIT3 (three bf16 pieces per float operand, bf16 matrix pipe; passes of 33-64 pairs): the same bounds
+# "f32_split" = EKF_ARITH_SPLIT3 (three bf16 pieces per float operand, bf16 matrix pipe; passes of 28-64 pairs): the same bounds
 BOUNDS = {"f32": (2e-9, 6e-12, 1e-9, 2e-12), "f32_mixed": (2e-9, 6e-12, 1e-9, 2e-12), "f32_split": (2e-9, 6e-12, 1e-9, 2e-12)}
 
 

@@ -13,7 +13,7 @@ What is asserted, and against what:
     as close: the split sum's error is not larger than the fmaf chain's (entry by entry against an F64 sum at 40 000 landmarks:
     scripts/probes/flush32_bench.hip ACC=1, profiles/round4_tuning.md 53: max 3.6 against 4.7, mean 0.21 against 0.28 float ulps of sum |k g|);
   * sharding changes where a tile is updated, not one operation on it: bit-identical to the plain engine.
-Passes of up to 32 pairs run the F32-arithmetic kernels (the pass is HBM-bound there either way)."""
+Passes of up to 27 pairs run the F32-arithmetic kernels (faster there: the pass is HBM-bound either way)."""
 import numpy as np
 import pytest
 
@@ -53,7 +53,7 @@ def _run(engines, ref, steps, seed, appends=()):
                 ref.append(u, R, pos, ref.N + 1)
 
 
-@pytest.mark.parametrize("batch", [33, 40, 50, 64])
+@pytest.mark.parametrize("batch", [28, 33, 40, 50, 64])
 def test_split_arithmetic_pass_against_f64_oracle(batch, oracle_lib):
     from ekf_slam_amd import Engine
     from oracle.ekf_structured import StructuredEKF
