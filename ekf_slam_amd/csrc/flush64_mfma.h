@@ -22,12 +22,15 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // where the f64 MFMA rate (measured 44-48 TFLOP/s, scripts/probes/mfma_f64_rate.hip) is the limit.
 // Storage: f64 tiles with T = 128 (a work item = 64 rows x the 128 columns of a tile) and f32 tiles with T = 256 (a work item
 // = 64 rows x one 128-column half; a lane's 16 bytes are 4 columns, widened to f64 on load and rounded once on store).
-template <typename TS, int T, int kChunk, int kCols = 128, int kWpe = (kChunk <= 4 ? 4 : 3)>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
+// kWaves: wavefronts per workgroup = 16-row groups per work item (4: the production shape; 8: 128-row items, G staged once per 128 rows -- measured,
+// round4_tuning.md 58); kAbl (tuning builds only): 1 = no matrix work, 2 = no operand staging either (the item shape as a plain copy).
+template <typename TS, int T, int kChunk, int kCols = 128, int kWpe = (kChunk <= 4 ? 4 : 3), int kWaves = 4, int kAbl = 0>
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
 void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2 *__restrict__ work, int64_t nwork,
                   const double *__restrict__ Kp, const double *__restrict__ Gp, int64_t pair_stride, int pstart, int pcap,
                   int npairs, TileMap tm) {
-    constexpr int kRows = 64, kKPad = kRows + 16;
+    constexpr int kBlock = 64 * kWaves;                               // (shadows the file-scope constant: this kernel's own workgroup size)
+    constexpr int kRows = 16 * kWaves, kKPad = kRows + 16;
     constexpr int kE = 16 / (int)sizeof(TS);                          // columns in a lane's 16 bytes: 2 (f64) or 4 (f32)
     constexpr int kBP = kCols / (16 * kE);                            // 16-byte column groups per lane and row: 4 or 2
     constexpr int kColParts = T / kCols, kSubsPerTile = (T / kRows) * kColParts;
@@ -73,12 +76,12 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
 #pragma unroll
             for (int q = 0; q < kPerK; ++q) {
                 const int e = tid + q * kBlock, row = e & (kRows - 1);
-                const int i = (e >> 6) < cn ? (e >> 6) : cn - 1;
+                const int i = (e / kRows) < cn ? (e / kRows) : cn - 1;
                 tk[q] = reinterpret_cast<const double2 *>(Kp + (int64_t)ring_slot(pstart, c0 + i, pcap) * pair_stride)[krow0 + row];
             }
         };
-        fetch(0, npairs < kChunk ? npairs : kChunk);
-        for (int c0 = 0; c0 < npairs; c0 += kChunk) {
+        if constexpr (kAbl < 2) fetch(0, npairs < kChunk ? npairs : kChunk);
+        for (int c0 = 0; kAbl < 2 && c0 < npairs; c0 += kChunk) {
             const int cn = npairs - c0 < kChunk ? npairs - c0 : kChunk;
             __syncthreads();                                          // everyone is done with the previous chunk
 #pragma unroll
@@ -89,13 +92,13 @@ void k_flush_mfma(const TS *__restrict__ tiles, TS *__restrict__ dst, const int2
             }
 #pragma unroll
             for (int q = 0; q < kPerK; ++q) {
-                const int e = tid + q * kBlock, i = e >> 6, row = e & (kRows - 1);
+                const int e = tid + q * kBlock, i = e / kRows, row = e & (kRows - 1);
                 if (i < cn) { Ks[2 * i][row] = -tk[q].x; Ks[2 * i + 1][row] = -tk[q].y; }
                 else if (i == cn) { Ks[2 * i][row] = -0.0; Ks[2 * i + 1][row] = -0.0; }
             }
             __syncthreads();
             if (c0 + kChunk < npairs) fetch(c0 + kChunk, npairs - c0 - kChunk < kChunk ? npairs - c0 - kChunk : kChunk);
-            const int ksteps = (cn + 1) >> 1;                         // two pairs = four rank-1 terms per MFMA
+            const int ksteps = kAbl ? 0 : (cn + 1) >> 1;              // two pairs = four rank-1 terms per MFMA
 #pragma unroll 2
             for (int ks = 0; ks < ksteps; ++ks) {
                 const double a = Ks[4 * ks + lr][wave * 16 + lc];

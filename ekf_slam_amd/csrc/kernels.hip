@@ -303,12 +303,44 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
             if (npairs <= half_max) {
                 int64_t g2 = 8 * xcd_len * (T / 64) * (T / 64);
                 if (grid_cap > 0 && g2 > grid_cap) g2 = grid_cap;
+#ifdef EKF_TUNING
+#define EKF_F64H(WPE) do { hipLaunchKernelGGL((k_flush_mfma<TS, T, 4, 64, WPE>), dim3((unsigned)g2), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv, \
+                                   work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                if (kname) snprintf(kname, 64, "k_flush_mfma<double,%d,4,64,wpe%d>", T, WPE); return true; } while (0)
+                switch (ekf_tune_int("EKF_FLUSH_HALF_WPE", 5)) {      // sweep 58: fewer wavefronts per SIMD = a narrower window of addresses in flight
+                    case 2: EKF_F64H(2);
+                    case 3: EKF_F64H(3);
+                    case 4: EKF_F64H(4);
+                    default: break;
+                }
+#undef EKF_F64H
+#endif
                 hipLaunchKernelGGL((k_flush_mfma<TS, T, 4, 64, 5>), dim3((unsigned)g2), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
                                    work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
                 if (kname) snprintf(kname, 64, "k_flush_mfma<double,%d,4,64>", T);
                 return true;
             }
         }
+#ifdef EKF_TUNING
+        if constexpr (sizeof(TS) == 8) {                              // sweep 58: 128-row items (eight wavefronts), ablations of the production shape
+            const int v = 100 * ekf_tune_int("EKF_FLUSH_WAVES", 4) + 10 * ekf_tune_int("EKF_FLUSH_CHUNK", npairs <= chunk_switch ? 4 : 8) + ekf_tune_int("EKF_FLUSH_ABL", 0);
+#define EKF_F64V(CH, WPE, WAVES, ABL) do { int64_t gv = 8 * xcd_len * (T / (16 * WAVES)); if (grid_cap > 0 && gv > grid_cap) gv = grid_cap; \
+                hipLaunchKernelGGL((k_flush_mfma<TS, T, CH, 128, WPE, WAVES, ABL>), dim3((unsigned)gv), dim3(64 * WAVES), 0, s, (const TS *)st.tiles, (TS *)dstv, \
+                                   work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm); \
+                if (kname) snprintf(kname, 64, "k_flush_mfma<double,%d,%d,w%d,abl%d>", T, CH, WAVES, ABL); return true; } while (0)
+            switch (v) {
+                case 340: EKF_F64V(4, 3, 4, 0);                       // (the hundreds digit 3: the production shape at three wavefronts per SIMD)
+                case 441: EKF_F64V(4, 4, 4, 1);
+                case 442: EKF_F64V(4, 4, 4, 2);
+                case 840: EKF_F64V(4, 4, 8, 0);
+                case 880: EKF_F64V(8, 4, 8, 0);
+                case 841: EKF_F64V(4, 4, 8, 1);
+                case 842: EKF_F64V(4, 4, 8, 2);
+                default: break;
+            }
+#undef EKF_F64V
+        }
+#endif
         if (npairs <= chunk_switch)
             hipLaunchKernelGGL((k_flush_mfma<TS, T, 4>), dim3((unsigned)grid), dim3(kBlock), 0, s, (const TS *)st.tiles, (TS *)dstv,
                                work_xcd, xcd_len, st.Kp, st.Gp, st.pair_stride, pstart, st.pcap, npairs, st.tm);
