@@ -16,6 +16,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -212,6 +213,19 @@ static void name_kernel(char *out, const char *base, size_t elt, int T, int p3, 
     else snprintf(out, 64, "%s<%s,%d,%d,%s>", base, elt == 8 ? "double" : "float", T, p3, xcd ? "true" : "false");
 }
 
+// Dynamic LDS beyond 64 KiB has to be allowed per kernel AND per device (a ShardGroup drives several devices from one process): set once for
+// the device that is current at the launch, remembered in a bit mask.
+static hipError_t allow_dynamic_lds(const void *fn, size_t bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+
 // the MFMA flush for the (storage type, tile edge) pairs it exists for; false: not applicable, use the VALU kernels
 template <typename TS, int T>
 static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_xcd, int64_t xcd_len, int pstart, int npairs,
@@ -233,8 +247,8 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                 // cfg.pass_arith = EKF_ARITH_SPLIT3, 28-64 pairs (below, the F32 kernels are the faster ones: 20 pairs 4.27 against 4.75 ms at 40 000 landmarks, 32
                 // pairs 5.08 against 4.74 -- round4_tuning.md 57): the float copies cut into three bf16 planes (logical pair order, zeros beyond
                 // npairs), then the strip form of the pass on the bf16 matrix pipe (flush32_split.h) -- bound by HBM, not by the matrix pipe
-                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_split3<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                   ekf_pipe32::lds_bytes_split());
+                static std::atomic<uint64_t> lds_ok{0};
+                const hipError_t attr = allow_dynamic_lds((const void *)ekf_pipe32::k_flush_split3<2>, ekf_pipe32::lds_bytes_split(), lds_ok);
                 if (attr == hipSuccess) {
                     hipLaunchKernelGGL(ekf_pipe32::k_split_pairs, dim3((unsigned)(aux->cols / 256), ekf_pipe32::kKB, 2), dim3(256), 0, s, (const float *)st.Kp32,
                                        (const float *)st.Gp32, aux->Kb3, aux->Gb3, st.pair_stride, st.ldm, aux->cols, pstart, st.pcap, npairs);
@@ -249,8 +263,8 @@ static bool launch_flush_mfma(const DevState &st, void *dstv, const int2 *work_x
                 // 57-64 pairs (eight stages of eight): the strip form -- one persistent workgroup per CU walks row strips with -K in its
                 // wavefronts' registers and a whole item's G double-buffered in LDS (flush32_pipe.h): 7.3 ms against 8.1-8.3 at 40 000
                 // landmarks and 64 pairs, same bits
-                static const hipError_t attr = hipFuncSetAttribute((const void *)ekf_pipe32::k_flush_strip32<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                   ekf_pipe32::lds_bytes_strip<8>());
+                static std::atomic<uint64_t> lds_ok{0};
+                const hipError_t attr = allow_dynamic_lds((const void *)ekf_pipe32::k_flush_strip32<8>, ekf_pipe32::lds_bytes_strip<8>(), lds_ok);
                 if (attr == hipSuccess) {
                     hipLaunchKernelGGL((ekf_pipe32::k_flush_strip32<8>), dim3((unsigned)aux->grid), dim3(512), ekf_pipe32::lds_bytes_strip<8>(), s,
                                        (const float *)st.tiles, (float *)dstv, aux->segs, aux->nsegs, (const float *)st.Kp32, (const float *)st.Gp32, st.pair_stride,
