@@ -24,6 +24,16 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ inline d2 ldnt(const double *p) { return __builtin_nontemporal_load(reinterpret_cast<const d2 *>(p)); }
 __device__ inline void stnt(double *p, d2 v) { __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(p)); }
 
+template <int kWpe>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
+void k_rows_w(double *t, int64_t n16) {                                    // variant 0 at a given occupancy
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    d2 v = ldnt(t + 2 * i);
+    v += 1.0;
+    stnt(t + 2 * i, v);
+}
+
 __global__ __launch_bounds__(256) void k_rows(double *t, int64_t n16) {   // variant 0
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n16) return;
@@ -258,6 +268,10 @@ int main(int argc, char **argv) {
     const int64_t n16 = elems / 2, it128 = ntiles * 2, it64 = ntiles * 4;
     for (int round = 0; round < 2; ++round) {
         timeit("0 rows, 4 KiB workgroups", [&] { hipLaunchKernelGGL(k_rows, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, t, n16); });
+        timeit("0 rows, wpe 2", [&] { hipLaunchKernelGGL((k_rows_w<2>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, t, n16); });
+        timeit("0 rows, wpe 3", [&] { hipLaunchKernelGGL((k_rows_w<3>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, t, n16); });
+        timeit("0 rows, wpe 4", [&] { hipLaunchKernelGGL((k_rows_w<4>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, t, n16); });
+        timeit("0 rows, wpe 6", [&] { hipLaunchKernelGGL((k_rows_w<6>), dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, t, n16); });
         timeit("1 64x128 items, wpe 4", [&] { hipLaunchKernelGGL((k_item<128, 4>), dim3((unsigned)it128), dim3(256), 0, 0, t, it128); });
         timeit("2 64x64 items, wpe 5", [&] { hipLaunchKernelGGL((k_item<64, 5>), dim3((unsigned)it64), dim3(256), 0, 0, t, it64); });
         timeit("2 64x64 items, wpe 2", [&] { hipLaunchKernelGGL((k_item<64, 2>), dim3((unsigned)it64), dim3(256), 0, 0, t, it64); });
