@@ -80,7 +80,7 @@ struct ekf_handle {
     int32_t nfrozen = 0;       // pending pairs that belong to the in-flight flush (the oldest ones)
     bool inflight = false;
     hipStream_t flush_stream = nullptr;
-    hipEvent_t ev_pairs = nullptr, ev_flushed = nullptr;
+    hipEvent_t ev_pairs = nullptr, ev_flushed = nullptr, ev_rows = nullptr;
     hipEvent_t ev_xchg = nullptr;    // ekf_exchange_local: this shard's copies of one exchange are done
     // lazy predict: ekf_predict only records u; the next correction folds it into its gather kernel (one launch
     // instead of two, identical arithmetic); any other consumer of x / P launches k_predict first
@@ -170,6 +170,9 @@ struct ekf_handle {
     // the row-panel of landmark nx_idx, extracted by the last pass over P itself (ekf_hint_next + k_downdate_w<.., kNext>): valid while
     // the tiles, the map size and the send area stay as that pass left them and nothing is pending
     int64_t hint_idx = -1;         // ekf_hint_next: the landmark the NEXT ekf_correct will name
+    int64_t inflight_N = 0;      // cfg.async_flush: landmarks when the in-flight pass was launched (it writes rows < 2 * inflight_N) ...
+    bool appended_inflight = false;   // ... and whether landmarks were appended since (their rows are copied to the new store when it retires)
+    int flush_cus = 0;           // cfg.async_flush with a CU-masked pass stream: the CUs that stream may use (0: the whole device)
     bool nx_valid = false;
     int64_t nx_idx = -1, nx_N = 0;
     void *comm = nullptr;          // ncclComm_t
@@ -350,6 +353,17 @@ void colmajor2(const double R[4], double &r00, double &r01, double &r10, double 
 // its pairs leave the pending list.
 int32_t retire_inflight(ekf_handle *h) {
     if (!h->inflight) return EKF_OK;
+    if (h->appended_inflight) {
+        // Landmarks appended beside the pass (do_append) sit in the old store only: their rows go to the new one behind the pass, ON THE PASS'S
+        // STREAM -- the next pass follows in that stream's order (it does not wait for the main stream beyond ev_pairs) and must find them.
+        // The copy waits for the appends (main stream, all issued by now); the main stream then waits for the copy instead of the pass.
+        if (!h->ev_rows) HIPCHK(h, hipEventCreateWithFlags(&h->ev_rows, hipEventDisableTiming));
+        HIPCHK(h, hipEventRecord(h->ev_rows, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->flush_stream, h->ev_rows, 0));
+        HIPCHK(h, launch_copy_rows(h->st.tm, h->tilebuf[h->base], h->tilebuf[h->base ^ 1], 2 * h->inflight_N, 2 * h->N, h->storage, h->flush_stream));
+        HIPCHK(h, hipEventRecord(h->ev_flushed, h->flush_stream));
+        h->appended_inflight = false;
+    }
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_flushed, 0));
     h->base ^= 1;
     h->st.tiles = h->tilebuf[h->base];
@@ -509,6 +523,8 @@ int32_t batch_complete(ekf_handle *h) {
     HIPCHK(h, hipEventRecord(h->ev_flushed, h->flush_stream));
     h->nfrozen = h->npend;
     h->inflight = true;
+    h->inflight_N = h->N;
+    h->appended_inflight = false;
     return EKF_OK;
 }
 
@@ -594,10 +610,10 @@ int32_t enter(ekf_handle *h) {
 int32_t do_append(ekf_handle *h, const double u[2], const double R[4], const double pos[2], double signature,
                   const DevLoopArgs *dl = nullptr) {
     REQUIRE(h, h->N < h->cap, EKF_ERR_CAPACITY, "append: capacity_landmarks exhausted");
-    {
-        const int32_t rcp = retire_inflight(h);          // the new rows must land in the store every later kernel reads
-        if (rcp) return rcp;
-    }
+    // A pass in flight (cfg.async_flush) is not waited for: the new rows are written to the store the main stream reads (the one the pass
+    // reads too) and copied to the pass's output when it retires -- the pass leaves rows that did not exist at its launch as they are (its
+    // pairs have K = 0 there), and k_append writes nothing but the new landmark's own two rows of the tiles.
+    if (h->inflight) h->appended_inflight = true;
     AppendArgs a;
     a.u0 = u[0]; a.u1 = u[1];
     colmajor2(R, a.R00, a.R01, a.R10, a.R11);
@@ -1177,6 +1193,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
                             if (mask[bit >> 5] & (1u << (bit & 31))) { mask[bit >> 5] &= ~(1u << (bit & 31)); ++taken; }
                         }
                     HIPCHK(h, hipExtStreamCreateWithCUMask(&h->flush_stream, 8, mask));
+                    h->flush_cus = ncu - taken;                                // what a persistent pass kernel on that stream can occupy
                 } else {
                     int lo = 0, hi = 0;
                     HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1203,6 +1220,7 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
         hipDeviceProp_t prop;
         HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
         h->aux.grid = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (h->flush_cus > 0) h->aux.grid = h->flush_cus;                 // cfg.async_flush: one persistent workgroup per CU of the pass stream's mask
         h->aux.grid -= h->aux.grid % 8;                                   // (block b walks XCD stream b & 7)
         if (h->aux.grid < 8) h->aux.grid = 8;
         const int64_t ranges = (2 * nt_cap + ekf_pipe32::kSeg * world - 1) / (ekf_pipe32::kSeg * world);
@@ -1298,6 +1316,7 @@ int32_t ekf_destroy(ekf_handle *h) {
     if (h->ev_xchg) hipEventDestroy(h->ev_xchg);
     if (h->ev_pairs) hipEventDestroy(h->ev_pairs);
     if (h->ev_flushed) hipEventDestroy(h->ev_flushed);
+    if (h->ev_rows) hipEventDestroy(h->ev_rows);
     for (auto &t : h->timers) for (hipEvent_t e : t.ev) hipEventDestroy(e);
     for (void *p : h->allocs) hipFree(p);
     if (h->h_decision) hipHostFree(h->h_decision);

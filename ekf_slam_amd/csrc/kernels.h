@@ -216,6 +216,8 @@ hipError_t launch_associate(const DevState &st, const AssocArgs &a, double *pos_
 hipError_t launch_assoc_merge(const DevState &st, const double *recv, int world, int64_t count, int64_t N, bool want_costs,
                               double *pos_cost, AssocDecision *decision, AssocDecision *host_decision, int seq, hipStream_t s);
 // dense (column-major, n x n, device) <-> tiled
+// cfg.async_flush: rows [r0, r1) of the landmark block (every local tile of the tile rows they lie in) copied from one tile store to the other
+hipError_t launch_copy_rows(const TileMap &tm, const void *src, void *dst, int64_t r0, int64_t r1, int storage, hipStream_t s);
 hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s);
 hipError_t launch_pack_dense(const DevState &st, int cur, int64_t n_mm, const double *dense, int storage, hipStream_t s);
 hipError_t launch_get_block(const DevState &st, int cur, int64_t r0, int64_t c0, int64_t nr, int64_t nc,

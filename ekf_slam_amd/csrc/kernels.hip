@@ -506,6 +506,23 @@ hipError_t launch_assoc_merge(const DevState &st, const double *recv, int world,
     return hipGetLastError();
 }
 
+hipError_t launch_copy_rows(const TileMap &tm, const void *src, void *dst, int64_t r0, int64_t r1, int storage, hipStream_t s) {
+    if (r1 <= r0) return hipSuccess;
+    const int T = tm.T;
+    if (T > kBlock * (storage == 0 ? 2 : 4)) return hipErrorInvalidValue;                    // a tile row must fit one workgroup's lanes
+    for (int64_t I = r0 >> tm.shift; I <= (r1 - 1) >> tm.shift; ++I) {
+        const int64_t lo = std::max<int64_t>(r0, I * T) - I * T, hi = std::min<int64_t>(r1, (I + 1) * T) - I * T;
+        const int64_t slot0 = tm.row_base(I), nslots = tm.row_base(I + 1) - slot0;
+        if (nslots <= 0 || hi <= lo) continue;
+        const int lanes = T / (storage == 0 ? 2 : 4), per_wg = kBlock / lanes > 0 ? kBlock / lanes : 1;
+        const int64_t grid = cdiv(nslots * (hi - lo), per_wg);
+        EKF_STORAGE_DISPATCH(storage,
+            hipLaunchKernelGGL(k_copy_tile_rows<double>, dim3((unsigned)grid), dim3(kBlock), 0, s, (const double *)src, (double *)dst, slot0, nslots, (int)lo, (int)(hi - lo), T),
+            hipLaunchKernelGGL(k_copy_tile_rows<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, (const float *)src, (float *)dst, slot0, nslots, (int)lo, (int)(hi - lo), T));
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_unpack_dense(const DevState &st, int cur, int64_t n_mm, double *dense, int storage, hipStream_t s) {
     const int64_t n = n_mm + 3;
     const int64_t grid = cdiv(n * n, kBlock);

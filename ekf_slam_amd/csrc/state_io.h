@@ -164,4 +164,24 @@ __global__ __launch_bounds__(kBlock) void k_digest(DevState st, int cur, int64_t
     if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
 }
 
+// cfg.async_flush: landmarks appended WHILE a pass is in flight were written (k_append) to the store that pass reads; the pass's own image of
+// those rows in the store it writes is stale (it may have read a tile before the append reached it) -- and is the identity anyway, every pending
+// pair of that pass having K = 0 on rows that did not exist when it was recorded.  When the pass retires, rows [lrow0, lrow0 + nrows) of every
+// local tile of one tile row (slots slot0 .. slot0 + nslots - 1) are copied from the old store to the new one: 16 bytes per lane.
+template <typename TS>
+__global__ __launch_bounds__(kBlock) void k_copy_tile_rows(const TS *__restrict__ src, TS *__restrict__ dst, int64_t slot0, int64_t nslots,
+                                                         int lrow0, int nrows, int T) {
+    constexpr int kE = 16 / (int)sizeof(TS);
+    const int lanes = T / kE;                                           // 16-byte pieces of a tile row (T >= 16: at least 2)
+    const int per_wg = kBlock / lanes > 0 ? kBlock / lanes : 1;         // tile rows one workgroup copies
+    const int sub = (int)threadIdx.x / lanes, piece = (int)threadIdx.x - sub * lanes;
+    const int64_t item = (int64_t)blockIdx.x * per_wg + sub;            // (slot, row)
+    if (sub >= per_wg || item >= nslots * nrows) return;
+    const int64_t slot = slot0 + item / nrows;
+    const int row = lrow0 + (int)(item % nrows);
+    const int64_t off = slot * (int64_t)T * T + (int64_t)row * T + (int64_t)piece * kE;
+    typedef TS v16_t __attribute__((ext_vector_type(kE)));
+    *reinterpret_cast<v16_t *>(dst + off) = *reinterpret_cast<const v16_t *>(src + off);
+}
+
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

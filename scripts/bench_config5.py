@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=12, help="12 is the usable point of the F64-arithmetic pass on float tiles; 32-64 with --storage f32_mixed")
+    ap.add_argument("--async-flush", action="store_true", help="cfg.async_flush: the pass on a second, CU-masked stream beside the next batch's corrections (twice the tile memory)")
     ap.add_argument("--storage", default="f32", help="f32: float tiles, F64 arithmetic; f32_mixed: float tiles, the pass in F32 arithmetic (cfg.pass_arith); f32_split: the same in split arithmetic (every float operand cut into three bfloat16 pieces, bf16 matrix pipe); f64")
     args = ap.parse_args()
     from ekf_slam_amd import Engine, _lib as L
@@ -60,7 +61,7 @@ def main():
     d = rng.uniform(0.01, 0.1, n0)
     U = rng.normal(0.0, 0.01, (n0, 8))
     s = np.arange(1, N0 + 1.0)
-    e = Engine(mode="known", capacity=cap, storage=args.storage, batch=args.batch)
+    e = Engine(mode="known", capacity=cap, storage=args.storage, batch=args.batch, async_flush=args.async_flush)
     t0 = time.perf_counter()
     e.load_lowrank_state(x, s, d, U)
     e.sync()

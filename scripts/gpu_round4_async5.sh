@@ -1,0 +1,9 @@
+#!/bin/bash
+# GPU box: configs[4] (40 000 landmarks, batch 64, split arithmetic) with the pass beside the next batch's corrections (cfg.async_flush)
+# against the synchronous schedule, same call.  profiles/round4_tuning.md 59.
+set -o pipefail
+O=gpurun_out/round4_async5.log
+: > $O
+( timeout -k 10 200 python -m pytest tests/test_f32_split_gpu.py tests/test_f32_mixed_gpu.py -x -q -m gpu \
+  && for A in "" "--async-flush" "" "--async-flush"; do timeout -k 10 200 python scripts/bench_config5.py --landmarks 40000 --steps 1024 --warmup 128 --batch 64 --storage f32_split $A || exit 1; done \
+  && for A in "" "--async-flush"; do timeout -k 10 200 python scripts/bench_config5.py --landmarks 40000 --steps 1024 --warmup 128 --batch 64 --storage f32_mixed $A || exit 1; done ) 2>&1 | tee -a $O

@@ -392,3 +392,42 @@ def test_diag_blocks_are_live_without_a_pass(storage, tile):
             if step == 5:
                 ref.append([0.1, 2.0], np.diag([.2, 40.0]), [3.0, -4.0], N + 1)
         np.testing.assert_array_equal(ref.get_P(), Pf)
+
+
+@pytest.mark.parametrize("batch,tile,world", [(4, 16, 1), (8, 16, 1), (16, 32, 1), (3, 16, 1), (8, 16, 3)])
+def test_async_pass_with_an_append_every_step_equals_immediate_bitwise(batch, tile, world, oracle_lib):
+    """configs[4]'s step (predict + append + correct, EKF_SLAM.m:67-98 then :124-145) on the asynchronous engine: landmarks appended WHILE a
+    pass is in flight go to the store the pass reads and are copied to the store it writes when it retires (k_copy_tile_rows) -- the append
+    does not wait for the pass.  Rows cross several tile edges per batch (tile 16: 8 landmarks per tile row); F64 tiles: bit-identical."""
+    from ekf_slam_amd import Engine
+    from ekf_slam_amd.sharding import ShardGroup
+    from oracle.ekf_structured import StructuredEKF
+    N, steps = 21, 70
+    x, P, s = _state(N, 43)
+    imm = Engine(capacity=N + steps, tile=tile, batch=1)
+    asy = (Engine(capacity=N + steps, tile=tile, batch=batch, async_flush=True) if world == 1 else
+           ShardGroup(world, capacity=N + steps, tile=tile, batch=batch, async_flush=True))
+    ref = StructuredEKF(N + steps, "known")
+    for e in (imm, asy, ref):
+        e.set_state(x, P, s)
+    rng = np.random.default_rng(9)
+    for step in range(steps):
+        u = [0.1, 3.0]
+        pos, sig = rng.uniform(-5, 5, 2), imm.N + 1
+        Ra = np.diag([0.2, 40.0])
+        idx0 = int(rng.integers(0, imm.N + 1))                          # now and then the landmark appended in this very step
+        z = [rng.uniform(1, 30), rng.uniform(1, 359)]
+        R = np.diag([z[0] * .01, z[1] * 5.0])
+        for e in (imm, asy, ref):
+            e.predict(u)
+            e.append(u, Ra, pos, sig)
+            e.correct(z, R, idx0 + (1 if e is ref else 0))
+        if step % 9 == 4:
+            np.testing.assert_array_equal(asy.get_x(), imm.get_x())
+        if step == 40:                                                   # a read in the middle: retires the pass in flight, copies the rows
+            np.testing.assert_array_equal(asy.get_P(), imm.get_P())
+    assert asy.N == imm.N == N + steps
+    Pi = imm.get_P()
+    np.testing.assert_array_equal(asy.get_x(), imm.get_x())
+    np.testing.assert_array_equal(asy.get_P(), Pi)
+    assert rel_err(Pi, ref.P) < REL and rel_err(imm.get_x(), ref.x) < REL
