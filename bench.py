@@ -176,7 +176,13 @@ def other_configs(timeout_s=300):
             # the same workload with the pass in split arithmetic (cfg.pass_arith = EKF_ARITH_SPLIT3: three bf16 pieces per float operand,
             # six exact partial products, float accumulation -- the fmaf chain's error class, not its bits; flush32_split.h)
             ("configs[4] on one GPU, split arithmetic", ["scripts/bench_config5.py", "--storage", "f32_split", "--batch", "64", "--landmarks", "40000",
-                                                         "--steps", "9936", "--warmup", "64"]))
+                                                         "--steps", "9936", "--warmup", "64"]),
+            # both again with cfg.async_flush: the pass on a second, CU-masked stream beside the next batch's appends and corrections (twice the
+            # tile memory; with float tiles not the synchronous engine's bits -- tests/test_f32_mixed_gpu.py, tests/test_f32_split_gpu.py)
+            ("configs[4] on one GPU, asynchronous pass", ["scripts/bench_config5.py", "--storage", "f32_mixed", "--batch", "64", "--landmarks", "40000",
+                                                          "--steps", "9936", "--warmup", "64", "--async-flush"]),
+            ("configs[4] on one GPU, split arithmetic, asynchronous pass", ["scripts/bench_config5.py", "--storage", "f32_split", "--batch", "64",
+                                                                            "--landmarks", "40000", "--steps", "9936", "--warmup", "64", "--async-flush"]))
     out = {}
     for key, cmd in runs:
         try:

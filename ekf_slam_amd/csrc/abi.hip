@@ -1178,7 +1178,10 @@ int32_t ekf_create(const ekf_config *cfg, ekf_handle **out) {
                 // 12).  So the flush stream is confined to a CU mask that leaves `reserve` CUs (default 32 = 4 per XCD) to the
                 // gather chain.  Reserved set {32a + 8b + a}: 4 CUs on every XCD whether mask bits map to XCDs round-robin
                 // (bit % 8) or in blocks of 32.  (Tuning builds: EKF_ASYNC_RESERVE_CUS=0 gives a plain lowest-priority stream.)
-                int reserve = ekf_tune_int("EKF_ASYNC_RESERVE_CUS", 32);
+                // (Split arithmetic: 64 -- its pass is not bound by the matrix pipe and loses less to fewer CUs than the corrections gain from more:
+                // configs[4] at 40 000 landmarks 9.6 k update-steps/s against 8.8 k with 32 and 9.0 k synchronous; F32 arithmetic: 7.3 k with 32, 6.6 k
+                // with 64; counts that are not a multiple of 32 leave the persistent pass kernels two workgroups on some CU: round4_tuning.md 59.)
+                int reserve = ekf_tune_int("EKF_ASYNC_RESERVE_CUS", cfg->pass_arith == EKF_ARITH_SPLIT3 ? 64 : 32);
                 hipDeviceProp_t prop;
                 HIPCHK(h, hipGetDeviceProperties(&prop, cfg->device));
                 const int ncu = prop.multiProcessorCount;

@@ -147,7 +147,7 @@ def main():
            "ms_per_step": dt / args.steps * 1e3, "dtype": "f64 solve / %s" % {"f32": "f32 tiles, f64 pass arithmetic", "f32_mixed": "f32 tiles, f32 pass arithmetic (matrix pipe)", "f32_split": "f32 tiles, f32-equivalent split pass arithmetic (3 x bf16 pieces per operand, six exact partial products, f32 accumulation: bf16 matrix pipe)", "f64": "f64 tiles"}[args.storage], "data": "synthetic",
            "config": {"workload": "configs[4] shape on 1 GPU: %d -> %d landmarks, %s tile storage, F64 solve, step = predict + "
                                   "append + 1 correction (streaming landmark append)" % (N0 + args.warmup, e_N[0], args.storage),
-                      "deferred_batch": args.batch, "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
+                      "deferred_batch": args.batch, "async_flush": bool(args.async_flush), "tile": int(e.cfg.tile), "device_GB": e.device_bytes() / 1e9,
                       "bulk_load_s": t_load, "state_finite": finite},
            "roofline": roof}
     print(json.dumps(out), flush=True)

@@ -13,8 +13,8 @@ if "cpu_baseline" in b:
     print("cpu       %8.1f %s on %d cores (%s)" % (b["cpu_baseline"]["value"], b["cpu_baseline"]["unit"], b["cpu_baseline"]["cores"], b["cpu_baseline"]["kind"]))
 for k, c in b.get("other_configs", {}).items():
     if "error" in c:
-        print("%-40s ERROR %s" % (k, str(c["error"])[:80]))
+        print("%-58s ERROR %s" % (k, str(c["error"])[:80]))
         continue
     r = c.get("roofline") or {}
-    print("%-40s %8.0f steps/s  %s" % (k, c["value"], ("%s  launch %.3f ms  bound %s %.3f" % (r["kernel"], r["avg_launch_ms"], r["bound"], r["frac"])) if r else ""))
+    print("%-58s %8.0f steps/s  %s" % (k, c["value"], ("%s  launch %.3f ms  bound %s %.3f" % (r["kernel"], r["avg_launch_ms"], r["bound"], r["frac"])) if r else ""))
 print("n_gpus", b["n_gpus"], "transport", b["config"]["transport"], "digest", b["config"]["state_digest"])

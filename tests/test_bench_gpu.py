@@ -42,3 +42,8 @@ def test_default_bench_line_carries_the_other_single_gpu_configurations():
     assert c4s["config"]["state_finite"] and r4s["kernel"] == "k_flush_split3<2>" and r4s["pairs_per_launch"] == 64
     assert r4s["bound"] == "hbm" and r4s["roofs"]["mfma"]["executed_over_algorithmic_flops"] == 6.0 and r4s["roofs"]["mfma"]["peak"] == 2500.0
     assert c4s["steps"] == 9936 and c4s["value"] > 1.1 * c4["value"]
+    # both once more with the pass beside the next batch's appends and corrections (cfg.async_flush): present, finite, not slower than 0.9 x
+    for key, syn in (("configs[4] on one GPU, asynchronous pass", c4), ("configs[4] on one GPU, split arithmetic, asynchronous pass", c4s)):
+        ca = oc[key]
+        assert "error" not in ca, oc
+        assert ca["config"]["async_flush"] and ca["config"]["state_finite"] and ca["steps"] == 9936 and ca["value"] > 0.9 * syn["value"]
