@@ -79,7 +79,8 @@ typedef struct ekf_config {
                                     beside the gather (and, sharded, the exchange) of step i + 1.  Same bits as
                                     async_flush = 0 with F64 tiles (with F32 tiles the corrections beside a pass read its pairs
                                     unrounded where the synchronous engine reads the rounded tiles: equal within the F32 tolerance).  The second stream is confined to a CU mask that leaves 32 CUs
-                                    to the corrections.  Pays when a batch's corrections take
+                                    (64 with EKF_ARITH_SPLIT3) to the main stream.  ekf_append beside a pass does not wait for it
+                                    (the new rows reach the second store when the pass retires).  Pays when a batch's steps take
                                     about as long as its pass; with batch = 1 it has measured slower than the in-place
                                     pass at every map size on one GPU (two stores defeat the cache). */
     int32_t device_assoc;        /* EKF_MODE_UC, ekf_measure (EKF_SLAM_UC.m:107-151), when w_pos == 0 (the reference's live likelihood is
