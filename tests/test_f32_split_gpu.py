@@ -168,3 +168,32 @@ def test_split_arithmetic_unknown_correspondence_device_loop(oracle_lib):
     np.testing.assert_array_equal(dev.x, host.x)
     np.testing.assert_array_equal(dev.P, host.P)
     assert rel_err(dev.x, ref.x) < TOL_X and rel_err(dev.P, ref.P) < TOL_P
+
+
+@pytest.mark.parametrize("storage,batch", [("f32_split", 40), ("f32_split", 64), ("f32_mixed", 64)])
+def test_async_pass_with_an_append_every_step_on_float_tiles(storage, batch, oracle_lib):
+    """configs[4]'s step on the asynchronous engine with float tiles (tile edge 256): every step appends a landmark beside the pass in flight --
+    the new rows go to the store the pass reads and are copied to the other one when the pass retires (k_copy_tile_rows<float>), across the
+    tile-row edge at 1 280 rows.  Not the synchronous engine's bits (the corrections beside a pass read its pairs unrounded): both are held to
+    the F64 oracle at the float-tile tolerance, and to each other."""
+    from ekf_slam_amd import Engine
+    from oracle.ekf_structured import StructuredEKF
+    N = 560
+    steps = 3 * batch + 9                                     # 560 -> 560 + steps landmarks: rows 1 120 -> > 1 500
+    x, P, s = _state(N, 83)
+    syn = Engine(capacity=N + steps, storage=storage, batch=batch)
+    asy = Engine(capacity=N + steps, storage=storage, batch=batch, async_flush=True)
+    ref = StructuredEKF(N + steps, "known")
+    for q in (syn, asy, ref):
+        q.set_state(x, P, s)
+    _run([syn, asy], ref, steps, 23, appends=tuple(range(steps)))
+    assert syn.N == asy.N == ref.N == N + steps and 2 * N < 1280 < 2 * asy.N
+    xs, xa, Ps, Pa = syn.get_x(), asy.get_x(), syn.get_P(), asy.get_P()
+    # (one landmark appended per step with R up to diag(0.3, 1 800): after ~200 steps the float tiles are 1e-6 of max |P| from the oracle
+    # on BOTH engines -- the tolerance here is 3e-6, and the two engines must agree with each other as closely as with the oracle)
+    errs = dict(xa=rel_err(xa, ref.x), Pa=rel_err(Pa, ref.P), xs=rel_err(xs, ref.x), Ps=rel_err(Ps, ref.P), x_as=rel_err(xa, xs), P_as=rel_err(Pa, Ps))
+    assert max(errs["xa"], errs["xs"], errs["x_as"]) < 3 * TOL_X and max(errs["Pa"], errs["Ps"], errs["P_as"]) < 3 * TOL_P, errs
+    assert errs["Pa"] < 2 * errs["Ps"] + 1e-7, errs          # the asynchronous engine is not the less accurate one
+    # the appended landmarks' rows made it into the store that is current now: no zero rows where the oracle has entries
+    new_rows = slice(3 + 2 * N, 3 + 2 * asy.N)
+    assert np.abs(Pa[new_rows, :3 + 2 * N]).max() > 0 and rel_err(Pa[new_rows], ref.P[new_rows]) < 1e-5
