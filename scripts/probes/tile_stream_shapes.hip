@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <unistd.h>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -251,10 +252,12 @@ int main(int argc, char **argv) {
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     int ncu = 256;
     int64_t launches = 0;
+    const int cold_ms = getenv("COLD") ? atoi(getenv("COLD")) : 0;     // idle time in front of every timed block (and no warm-up launches then)
     auto timeit = [&](const char *name, auto launch) {
-        launches += 3 + reps;
-        for (int i = 0; i < 3; ++i) launch();
+        launches += (cold_ms ? 0 : 3) + reps;
+        if (!cold_ms) for (int i = 0; i < 3; ++i) launch();
         CHECK(hipDeviceSynchronize());
+        if (cold_ms) usleep(1000 * cold_ms);
         CHECK(hipEventRecord(e0));
         for (int i = 0; i < reps; ++i) launch();
         CHECK(hipEventRecord(e1));
