@@ -253,17 +253,32 @@ int main(int argc, char **argv) {
     int ncu = 256;
     int64_t launches = 0;
     const int cold_ms = getenv("COLD") ? atoi(getenv("COLD")) : 0;     // idle time in front of every timed block (and no warm-up launches then)
+    const int gap_us = getenv("GAP") ? atoi(getenv("GAP")) : -1;       // >= 0: launches timed one by one with that idle time in front of each
     auto timeit = [&](const char *name, auto launch) {
         launches += (cold_ms ? 0 : 3) + reps;
         if (!cold_ms) for (int i = 0; i < 3; ++i) launch();
         CHECK(hipDeviceSynchronize());
         if (cold_ms) usleep(1000 * cold_ms);
-        CHECK(hipEventRecord(e0));
-        for (int i = 0; i < reps; ++i) launch();
-        CHECK(hipEventRecord(e1));
-        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        if (gap_us >= 0) {                                              // every launch timed on its own, the chip idle for gap_us in front of it
+            for (int i = 0; i < reps; ++i) {
+                CHECK(hipDeviceSynchronize());
+                if (gap_us) usleep(gap_us);
+                CHECK(hipEventRecord(e0));
+                launch();
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float m1; CHECK(hipEventElapsedTime(&m1, e0, e1));
+                ms += m1;
+            }
+        } else {
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < reps; ++i) launch();
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
         CHECK(hipGetLastError());
-        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         ms /= reps;
         printf("%-44s %.4f ms  %.3f TB/s stored  (of 8 TB/s: %.3f)\n", name, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0);
         fflush(stdout);
