@@ -10,6 +10,7 @@
 //   3  64 x 64 items, persistent workgroups, the NEXT item's tile requested before this item's stores (wpe from argv)
 //   4  64 x 128 items, persistent, next item's tile requested before this item's stores (128 data registers: wpe <= 3)
 //   5  64 x 128 items, persistent, in two column halves: half B of this item / half A of the next in flight behind each half's stores
+//  10  64 x 128 items, one per workgroup, the four 32-column groups rolling (group g+1 requested before group g is stored)
 //   6  as 1, 16 x 128 per WAVEFRONT with 64-thread workgroups (no workgroup-level granularity at all)
 // Usage: tile_stream_shapes [landmarks=10000] [reps=20]
 #include <hip/hip_runtime.h>
@@ -234,6 +235,34 @@ void k_item_quarters(double *t, int64_t nitems) {
     }
 }
 
+// variant 10: 64 x 128 items, one item per workgroup (not persistent), the item's four 32-column groups rolling: group g+1 requested before group g
+// is stored -- what a pass with ALL pairs of an item staged in LDS (column-group-outer matrix loop) would stream like
+template <int kWpe>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kWpe, kWpe)))
+void k_item_rollq(double *t, int64_t nitems) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t it = blockIdx.x;
+    if (it >= nitems) return;
+    double *p = t + item_base<128>(it, wave, lane);
+    d2 a[4], b[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = ldnt(p + (4 * r) * T);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = ldnt(p + (4 * r) * T + 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stnt(p + (4 * r) * T, a[r] + 1.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[r] = ldnt(p + (4 * r) * T + 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stnt(p + (4 * r) * T + 32, b[r] + 1.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) b[r] = ldnt(p + (4 * r) * T + 96);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stnt(p + (4 * r) * T + 64, a[r] + 1.0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stnt(p + (4 * r) * T + 96, b[r] + 1.0);
+}
+
 __global__ void k_check(const double *t, int64_t n, double want, unsigned long long *bad) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n && t[i] != want) atomicAdd(bad, 1ull);
@@ -313,6 +342,10 @@ int main(int argc, char **argv) {
         timeit("9 64x128 persistent, rolling quarters +3, wpe 4", [&] { hipLaunchKernelGGL((k_item_quarters<4, 3>), dim3(ncu * 4), dim3(256), 0, 0, t, it128); });
         timeit("9 64x128 persistent, rolling quarters +3, wpe 8", [&] { hipLaunchKernelGGL((k_item_quarters<8, 3>), dim3(ncu * 8), dim3(256), 0, 0, t, it128); });
         timeit("9 64x128 persistent, rolling quarters +7, wpe 4", [&] { hipLaunchKernelGGL((k_item_quarters<4, 7>), dim3(ncu * 4), dim3(256), 0, 0, t, it128); });
+        timeit("10 64x128 items, rolling column groups, wpe 2", [&] { hipLaunchKernelGGL((k_item_rollq<2>), dim3((unsigned)it128), dim3(256), 0, 0, t, it128); });
+        timeit("10 64x128 items, rolling column groups, wpe 3", [&] { hipLaunchKernelGGL((k_item_rollq<3>), dim3((unsigned)it128), dim3(256), 0, 0, t, it128); });
+        timeit("10 64x128 items, rolling column groups, wpe 4", [&] { hipLaunchKernelGGL((k_item_rollq<4>), dim3((unsigned)it128), dim3(256), 0, 0, t, it128); });
+        timeit("10 64x128 items, rolling column groups, wpe 8", [&] { hipLaunchKernelGGL((k_item_rollq<8>), dim3((unsigned)it128), dim3(256), 0, 0, t, it128); });
         timeit("6 16x128 per 64-thread workgroup", [&] { hipLaunchKernelGGL(k_wave_item, dim3((unsigned)(it128 * 4)), dim3(64), 0, 0, t, it128 * 4); });
     }
     // every variant touches every element exactly once per launch: all elements must hold the same count
