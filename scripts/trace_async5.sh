@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/trace_async5
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT -o t --output-format csv -- python3 $REPO/scripts/bench_config5.py --landmarks 40000 --steps 384 --warmup 64 --batch 64 --storage ${STORAGE:-f32_split} --async-flush > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT -o t --output-format csv -- python3 $REPO/scripts/bench_config5.py --landmarks 40000 --steps 384 --warmup 64 --batch 64 --storage ${STORAGE:-f32_split} --async-flush > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]
